@@ -1,0 +1,157 @@
+"""ctypes binding of libfinrom_hip.so (include/finrom.h).  Thin by design: every batched
+operation of the hot path is one call into the HIP library.  There is NO CPU fallback --
+if the library is missing or a call fails, this module raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+
+
+class FinromError(RuntimeError):
+    pass
+
+
+class FomDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("nnzL", C.c_int32), ("npairs", C.c_int32), ("xdim", C.c_int32),
+                ("n_obs", C.c_int32), ("nasm", C.c_int32),
+                ("row_ptr", c_i32p), ("ent_col", c_i32p), ("pair_ptr", c_i32p), ("pair_a", c_i32p),
+                ("pair_b", c_i32p), ("asm_c0", c_f64p), ("asm_ptr", c_i32p), ("asm_idx", c_i32p),
+                ("asm_w", c_f64p), ("rhs", c_f64p), ("col_ptr", c_i32p), ("col_ent", c_i32p),
+                ("col_row", c_i32p), ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p),
+                ("perm", c_i32p)]
+
+
+class RomDesc(C.Structure):
+    _fields_ = [("n", C.c_int32), ("r", C.c_int32), ("P", C.c_int32), ("n_obs", C.c_int32),
+                ("nterms", C.c_int32),
+                ("row_ptr", c_i32p), ("term_p", c_i32p), ("term_val", c_f64p), ("rhs", c_f64p),
+                ("obs_phi", c_f64p)]
+
+
+# name -> (restype, argtypes); tests/test_abi.py checks every symbol of include/finrom.h is here
+SIGNATURES = {
+    "finrom_version": (C.c_int, []),
+    "finrom_last_error": (C.c_char_p, []),
+    "finrom_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "finrom_set_device": (C.c_int, [C.c_int]),
+    "finrom_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "finrom_free": (C.c_int, [C.c_void_p]),
+    "finrom_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "finrom_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "finrom_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "finrom_stream_sync": (C.c_int, [C.c_void_p]),
+    "finrom_profile_enable": (C.c_int, [C.c_int]),
+    "finrom_profile_reset": (C.c_int, []),
+    "finrom_profile_slots": (C.c_int, []),
+    "finrom_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "finrom_fom_create": (C.c_int, [C.POINTER(FomDesc), C.POINTER(C.c_void_p)]),
+    "finrom_fom_destroy": (None, [C.c_void_p]),
+    "finrom_fom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finrom_rom_create": (C.c_int, [C.POINTER(RomDesc), C.POINTER(C.c_void_p)]),
+    "finrom_rom_destroy": (None, [C.c_void_p]),
+    "finrom_rom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finrom_subfin_avg": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "finrom_sampler_create": (C.c_int, [c_f64p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "finrom_sampler_destroy": (None, [C.c_void_p]),
+    "finrom_sampler_draw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "finrom_sub": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.environ.get("FINROM_LIB", _build.LIB)
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise FinromError(
+                f"{path} not found: the HIP extension is not built "
+                "(run `python -m bayesianinferencedl_amd._build` or __graft_entry__.build()); "
+                "there is no CPU fallback for the hot path")
+        L = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.finrom_version() != 1:
+            raise FinromError("libfinrom_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().finrom_last_error().decode(errors="replace")
+        raise FinromError(f"{what or 'finrom call'} failed (status {rc}): {msg}")
+
+
+def i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(c_i32p)
+
+
+def f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(c_f64p)
+
+
+class DeviceBuffer:
+    """Device allocation owned by Python (finrom_malloc / finrom_free)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().finrom_malloc(C.byref(p), max(self.nbytes, 8)), "finrom_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a, stream=None):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        check(lib().finrom_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes, stream), "memcpy_h2d")
+        return b
+
+    def to_numpy(self, shape, dtype=np.float64, stream=None):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= max(self.nbytes, 8)
+        check(lib().finrom_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, stream), "memcpy_d2h")
+        return out
+
+    def zero(self, stream=None):
+        check(lib().finrom_memset(self.ptr, 0, self.nbytes, stream), "memset")
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().finrom_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def profile_read():
+    """-> {kernel name: (launches, total_ms)} from the library's HIP-event timers."""
+    L = lib()
+    out = {}
+    for s in range(L.finrom_profile_slots()):
+        name = C.c_char_p(); cnt = C.c_int64(); ms = C.c_double()
+        check(L.finrom_profile_read(s, C.byref(name), C.byref(cnt), C.byref(ms)))
+        out[name.value.decode()] = (cnt.value, ms.value)
+    return out

@@ -1,0 +1,367 @@
+// extern "C" surface of libfinrom_hip.so (see include/finrom.h for the contract).
+#include "finrom_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+
+namespace finrom {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+  return FINROM_ERR_HIP;
+}
+
+int Scratch::reserve(size_t bytes) {
+  if (bytes <= cap) return 0;
+  if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) { p = nullptr; set_error("hipMalloc of " + std::to_string(bytes) + " scratch bytes failed"); return FINROM_ERR_NOMEM; }
+  cap = bytes;
+  return 0;
+}
+void Scratch::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+
+// ---- profiling -------------------------------------------------------------------------
+static const char* kSlotNames[K_NUM] = {"pack", "fom_chol_solve", "unpack_w", "rom_proj_mfma",
+                                        "rom_reduced_solve", "subfin_avg", "sampler_gemm_exp", "misc"};
+struct Pending { int slot; hipEvent_t e0, e1; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<Pending> g_pending;
+static std::vector<hipEvent_t> g_pool;
+static double g_ms[K_NUM];
+static int64_t g_cnt[K_NUM];
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+ScopedKernelTimer::ScopedKernelTimer(int slot_, hipStream_t s_) : slot(slot_), s(s_) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on) return;
+  e0 = get_event(); e1 = get_event();
+  if (e0 && e1) (void)hipEventRecord(e0, s);
+}
+ScopedKernelTimer::~ScopedKernelTimer() {
+  if (!e0 || !e1) return;
+  (void)hipEventRecord(e1, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_pending.push_back({slot, e0, e1});
+}
+static void drain_pending() {
+  for (auto& p : g_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      g_ms[p.slot] += ms; g_cnt[p.slot] += 1;
+    }
+    g_pool.push_back(p.e0); g_pool.push_back(p.e1);
+  }
+  g_pending.clear();
+}
+
+int launch_subfin_avg(const double*, int, int, const double*, int64_t, double*, hipStream_t);
+int launch_sampler(const double*, int, const double*, int64_t, double*, hipStream_t);
+int launch_sub(const double*, const double*, int64_t, double*, hipStream_t);
+
+}  // namespace finrom
+
+using namespace finrom;
+
+struct finrom_fom_s {
+  FomDev d{};
+  std::vector<void*> owned;
+  Scratch xT, Lw, invd, yw;
+};
+struct finrom_rom_s {
+  RomDev d{};
+  std::vector<void*> owned;
+  Scratch Ar, Br;
+};
+struct finrom_sampler_s { double* U = nullptr; int n = 0; };
+
+template <class T>
+static int up(std::vector<void*>& owned, const T** dst, const T* host, size_t count) {
+  T* dp = nullptr;
+  int rc = upload(&dp, host, count);
+  if (rc) return rc;
+  if (dp) owned.push_back(dp);
+  *dst = dp;
+  return 0;
+}
+
+extern "C" {
+
+int finrom_version(void) { return FINROM_ABI_VERSION; }
+const char* finrom_last_error(void) { return g_err.c_str(); }
+
+int finrom_device_count(int* count) { if (!count) return FINROM_ERR_ARG; FR_HIP(hipGetDeviceCount(count)); return 0; }
+int finrom_set_device(int ordinal) { FR_HIP(hipSetDevice(ordinal)); return 0; }
+int finrom_malloc(void** dptr, size_t bytes) {
+  if (!dptr) return FINROM_ERR_ARG;
+  *dptr = nullptr;
+  if (bytes == 0) return 0;
+  hipError_t e = hipMalloc(dptr, bytes);
+  if (e != hipSuccess) { set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorName(e)); return FINROM_ERR_NOMEM; }
+  return 0;
+}
+int finrom_free(void* dptr) { if (dptr) FR_HIP(hipFree(dptr)); return 0; }
+int finrom_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes == 0) return 0;
+  FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  FR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+int finrom_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  if (bytes == 0) return 0;
+  FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  FR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+int finrom_memset(void* dst, int value, size_t bytes, void* stream) {
+  if (bytes == 0) return 0;
+  FR_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return 0;
+}
+int finrom_stream_sync(void* stream) { FR_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+int finrom_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_on = on != 0; return 0; }
+int finrom_profile_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  drain_pending();
+  for (int i = 0; i < K_NUM; ++i) { g_ms[i] = 0; g_cnt[i] = 0; }
+  return 0;
+}
+int finrom_profile_slots(void) { return K_NUM; }
+int finrom_profile_read(int slot, const char** name, int64_t* launches, double* total_ms) {
+  if (slot < 0 || slot >= K_NUM) return FINROM_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  drain_pending();
+  if (name) *name = kSlotNames[slot];
+  if (launches) *launches = g_cnt[slot];
+  if (total_ms) *total_ms = g_ms[slot];
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// FOM
+// ---------------------------------------------------------------------------------------
+int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
+  if (!a || !out) { set_error("fom_create: null argument"); return FINROM_ERR_ARG; }
+  *out = nullptr;
+  if (a->n <= 0 || a->nnzL < a->n || a->xdim <= 0 || a->n_obs < 0 || a->npairs < 0 || a->nasm < 0) {
+    set_error("fom_create: inconsistent sizes"); return FINROM_ERR_ARG;
+  }
+  // validate every index the kernel will dereference (a bad index would fault the GPU)
+  const int n = a->n, nnzL = a->nnzL;
+  auto bad = [&](const char* what) { set_error(std::string("fom_create: invalid ") + what); return FINROM_ERR_ARG; };
+  if (a->row_ptr[0] != 0 || a->row_ptr[n] != nnzL) return bad("row_ptr");
+  for (int i = 0; i < n; ++i) {
+    if (a->row_ptr[i + 1] <= a->row_ptr[i]) return bad("row_ptr (empty row)");
+    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e) {
+      const int c = a->ent_col[e];
+      const bool last = e == a->row_ptr[i + 1] - 1;
+      if (last ? c != i : (c < 0 || c >= i)) return bad("ent_col (row must end with its diagonal)");
+    }
+  }
+  if (a->pair_ptr[0] != 0 || a->pair_ptr[nnzL] != a->npairs) return bad("pair_ptr");
+  for (int e = 0; e < nnzL; ++e) {
+    if (a->pair_ptr[e + 1] < a->pair_ptr[e]) return bad("pair_ptr");
+    for (int q = a->pair_ptr[e]; q < a->pair_ptr[e + 1]; ++q)
+      if (a->pair_a[q] < 0 || a->pair_a[q] >= e || a->pair_b[q] < 0 || a->pair_b[q] >= e) return bad("pair_a/pair_b (must precede the entry)");
+  }
+  if (a->asm_ptr[0] != 0 || a->asm_ptr[nnzL] != a->nasm) return bad("asm_ptr");
+  for (int e = 0; e < nnzL; ++e) if (a->asm_ptr[e + 1] < a->asm_ptr[e]) return bad("asm_ptr");
+  for (int t = 0; t < a->nasm; ++t) if (a->asm_idx[t] < 0 || a->asm_idx[t] >= a->xdim) return bad("asm_idx");
+  if (a->col_ptr[0] != 0 || a->col_ptr[n] != nnzL - n) return bad("col_ptr");
+  for (int i = 0; i < n; ++i) {
+    if (a->col_ptr[i + 1] < a->col_ptr[i]) return bad("col_ptr");
+    for (int c = a->col_ptr[i]; c < a->col_ptr[i + 1]; ++c)
+      if (a->col_ent[c] < 0 || a->col_ent[c] >= nnzL || a->col_row[c] <= i || a->col_row[c] >= n) return bad("col_ent/col_row");
+  }
+  if (a->n_obs > 0) {
+    if (a->obs_ptr[0] != 0) return bad("obs_ptr");
+    for (int o = 0; o < a->n_obs; ++o) if (a->obs_ptr[o + 1] < a->obs_ptr[o]) return bad("obs_ptr");
+    for (int t = 0; t < a->obs_ptr[a->n_obs]; ++t) if (a->obs_idx[t] < 0 || a->obs_idx[t] >= n) return bad("obs_idx");
+  }
+  {
+    std::vector<char> seen(n, 0);
+    for (int i = 0; i < n; ++i) { int v = a->perm[i]; if (v < 0 || v >= n || seen[v]) return bad("perm"); seen[v] = 1; }
+  }
+
+  auto* h = new finrom_fom_s();
+  FomDev& d = h->d;
+  d.n = n; d.nnzL = nnzL; d.npairs = a->npairs; d.xdim = a->xdim; d.n_obs = a->n_obs;
+  int rc = 0;
+  const int nobsnz = a->n_obs > 0 ? a->obs_ptr[a->n_obs] : 0;
+  if (!rc) rc = up(h->owned, &d.row_ptr, a->row_ptr, n + 1);
+  if (!rc) rc = up(h->owned, &d.ent_col, a->ent_col, nnzL);
+  if (!rc) rc = up(h->owned, &d.pair_ptr, a->pair_ptr, nnzL + 1);
+  if (!rc) rc = up(h->owned, &d.pair_a, a->pair_a, a->npairs);
+  if (!rc) rc = up(h->owned, &d.pair_b, a->pair_b, a->npairs);
+  if (!rc) rc = up(h->owned, &d.asm_c0, a->asm_c0, nnzL);
+  if (!rc) rc = up(h->owned, &d.asm_ptr, a->asm_ptr, nnzL + 1);
+  if (!rc) rc = up(h->owned, &d.asm_idx, a->asm_idx, a->nasm);
+  if (!rc) rc = up(h->owned, &d.asm_w, a->asm_w, a->nasm);
+  if (!rc) rc = up(h->owned, &d.rhs, a->rhs, n);
+  if (!rc) rc = up(h->owned, &d.col_ptr, a->col_ptr, n + 1);
+  if (!rc) rc = up(h->owned, &d.col_ent, a->col_ent, nnzL - n);
+  if (!rc) rc = up(h->owned, &d.col_row, a->col_row, nnzL - n);
+  if (!rc) rc = up(h->owned, &d.obs_ptr, a->obs_ptr, a->n_obs + 1);
+  if (!rc) rc = up(h->owned, &d.obs_idx, a->obs_idx, nobsnz);
+  if (!rc) rc = up(h->owned, &d.obs_w, a->obs_w, nobsnz);
+  if (!rc) rc = up(h->owned, &d.perm, a->perm, n);
+  if (rc) { finrom_fom_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+void finrom_fom_destroy(finrom_fom_t h) {
+  if (!h) return;
+  for (void* p : h->owned) (void)hipFree(p);
+  h->xT.release(); h->Lw.release(); h->invd.release(); h->yw.release();
+  delete h;
+}
+
+int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, void* stream) {
+  if (!h || S < 0 || (S > 0 && (!x || (!qoi && h->d.n_obs > 0)))) { set_error("fom_solve: bad argument"); return FINROM_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const FomDev& d = h->d;
+  // bound the per-call workspace (L values dominate: nnzL * 8 B per sample)
+  const size_t per_sample = ((size_t)d.nnzL + 2 * (size_t)d.n + d.xdim) * sizeof(double);
+  int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
+  chunk = std::max<int64_t>(64, chunk / 64 * 64);
+  for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+    const int64_t Sc = std::min(chunk, S - s0);
+    const int64_t nblk = (Sc + 63) / 64;
+    int rc;
+    if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+    if ((rc = h->Lw.reserve((size_t)nblk * d.nnzL * 64 * sizeof(double)))) return rc;
+    if ((rc = h->invd.reserve((size_t)nblk * d.n * 64 * sizeof(double)))) return rc;
+    if ((rc = h->yw.reserve((size_t)nblk * d.n * 64 * sizeof(double)))) return rc;
+    if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
+    if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Lw.p, (double*)h->invd.p, (double*)h->yw.p,
+                         qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
+    if (w && (rc = launch_unpack_w(d, (const double*)h->yw.p, Sc, w + s0 * d.n, st))) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// ROM
+// ---------------------------------------------------------------------------------------
+int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
+  if (!a || !out) { set_error("rom_create: null argument"); return FINROM_ERR_ARG; }
+  *out = nullptr;
+  if (a->n <= 0 || a->r <= 0 || a->P < 0 || a->P > 31 || a->n_obs < 0 || a->nterms < 0) { set_error("rom_create: inconsistent sizes"); return FINROM_ERR_ARG; }
+  if (a->row_ptr[0] != 0 || a->row_ptr[a->n] != a->nterms) { set_error("rom_create: invalid row_ptr"); return FINROM_ERR_ARG; }
+  for (int i = 0; i < a->n; ++i) if (a->row_ptr[i + 1] < a->row_ptr[i]) { set_error("rom_create: invalid row_ptr"); return FINROM_ERR_ARG; }
+  for (int t = 0; t < a->nterms; ++t) if (a->term_p[t] < 0 || a->term_p[t] > a->P) { set_error("rom_create: invalid term_p"); return FINROM_ERR_ARG; }
+  const int r = a->r, NB = (r + 15) / 16, rp = 16 * NB;
+  if (NB > 8) { set_error("rom_create: basis size > 128 not supported yet"); return FINROM_ERR_UNSUPPORTED; }
+
+  // rows sorted by term count so that the 4 rows of a k-step need the same number of slots
+  std::vector<int> order(a->n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+    return (a->row_ptr[x + 1] - a->row_ptr[x]) > (a->row_ptr[y + 1] - a->row_ptr[y]); });
+  const int nk = (a->n + 3) / 4;
+  std::vector<int> kptr(nk + 1, 0);
+  std::vector<int2> slots;
+  std::vector<double> rhs4((size_t)nk * 4, 0.0);
+  for (int ks = 0; ks < nk; ++ks) {
+    int nt = 0;
+    for (int q = 0; q < 4; ++q) {
+      int idx = ks * 4 + q;
+      if (idx < a->n) { int row = order[idx]; nt = std::max(nt, a->row_ptr[row + 1] - a->row_ptr[row]); rhs4[idx] = a->rhs[row]; }
+    }
+    for (int t = 0; t < nt; ++t)
+      for (int q = 0; q < 4; ++q) {
+        int idx = ks * 4 + q;
+        int2 sl = make_int2(0, 0);          // padded zero r-vector, theta[0] = 1
+        if (idx < a->n) {
+          int row = order[idx];
+          int tt = a->row_ptr[row] + t;
+          if (tt < a->row_ptr[row + 1]) sl = make_int2((tt + 1) * rp, a->term_p[tt]);
+        }
+        slots.push_back(sl);
+      }
+    kptr[ks + 1] = kptr[ks] + nt;
+  }
+  std::vector<double> tv((size_t)(a->nterms + 1) * rp, 0.0);
+  for (int t = 0; t < a->nterms; ++t)
+    std::memcpy(&tv[(size_t)(t + 1) * rp], a->term_val + (size_t)t * r, r * sizeof(double));
+
+  auto* h = new finrom_rom_s();
+  RomDev& d = h->d;
+  d.n = a->n; d.r = r; d.rp = rp; d.NB = NB; d.P = a->P; d.n_obs = a->n_obs; d.nk = nk;
+  int rc = 0;
+  if (!rc) rc = up(h->owned, &d.kstep_ptr, kptr.data(), kptr.size());
+  if (!rc) rc = up(h->owned, &d.slot, slots.data(), slots.size());
+  if (!rc) rc = up(h->owned, &d.term_val, tv.data(), tv.size());
+  if (!rc) rc = up(h->owned, &d.rhs4, rhs4.data(), rhs4.size());
+  if (!rc) rc = up(h->owned, &d.obs_phi, a->obs_phi, (size_t)a->n_obs * r);
+  if (rc) { finrom_rom_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+void finrom_rom_destroy(finrom_rom_t h) {
+  if (!h) return;
+  for (void* p : h->owned) (void)hipFree(p);
+  h->Ar.release(); h->Br.release();
+  delete h;
+}
+
+int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r, double* qoi_r, double* A_r,
+                     double* B_r, int32_t* info, void* stream) {
+  if (!h || S < 0 || (S > 0 && (!theta || (!qoi_r && h->d.n_obs > 0)))) { set_error("rom_solve: bad argument"); return FINROM_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const RomDev& d = h->d;
+  const size_t per_sample = ((size_t)d.rp * d.rp + d.rp) * sizeof(double);
+  int64_t chunk = std::max<int64_t>(4, (int64_t)(((size_t)16 << 30) / per_sample) / 4 * 4);
+  for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+    const int64_t Sc = std::min(chunk, S - s0);
+    int rc;
+    if ((rc = h->Ar.reserve((size_t)Sc * d.rp * d.rp * sizeof(double)))) return rc;
+    if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
+    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, st))) return rc;
+    if ((rc = launch_rom_solve(d, (const double*)h->Ar.p, (const double*)h->Br.p, Sc, w_r ? w_r + s0 * d.r : nullptr,
+                               qoi_r ? qoi_r + s0 * d.n_obs : nullptr, A_r ? A_r + s0 * (int64_t)d.r * d.r : nullptr,
+                               B_r ? B_r + s0 * d.r : nullptr, info ? info + s0 : nullptr, st))) return rc;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n, const double* k, int64_t S, double* theta, void* stream) {
+  if (!Sop || P <= 0 || n <= 0 || S < 0 || (S > 0 && (!k || !theta))) { set_error("subfin_avg: bad argument"); return FINROM_ERR_ARG; }
+  return launch_subfin_avg(Sop, P, n, k, S, theta, (hipStream_t)stream);
+}
+
+int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out) {
+  if (!U || n <= 0 || !out) { set_error("sampler_create: bad argument"); return FINROM_ERR_ARG; }
+  auto* h = new finrom_sampler_s();
+  h->n = n;
+  int rc = upload(&h->U, U, (size_t)n * n);
+  if (rc) { delete h; return rc; }
+  *out = h;
+  return 0;
+}
+void finrom_sampler_destroy(finrom_sampler_t h) { if (!h) return; if (h->U) (void)hipFree(h->U); delete h; }
+int finrom_sampler_draw(finrom_sampler_t h, const double* xi, int64_t S, double* k, void* stream) {
+  if (!h || S < 0 || (S > 0 && (!xi || !k))) { set_error("sampler_draw: bad argument"); return FINROM_ERR_ARG; }
+  return launch_sampler(h->U, h->n, xi, S, k, (hipStream_t)stream);
+}
+
+int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {
+  if (count < 0 || (count > 0 && (!a || !b || !out))) { set_error("sub: bad argument"); return FINROM_ERR_ARG; }
+  return launch_sub(a, b, count, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

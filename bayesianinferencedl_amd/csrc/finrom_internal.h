@@ -1,0 +1,83 @@
+// Internal declarations shared by the translation units of libfinrom_hip.so (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "finrom.h"
+
+namespace finrom {
+
+constexpr int WAVE = 64;  // gfx950 wavefront; the batch is blocked in groups of 64 samples
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define FR_HIP(call)                                        \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return finrom::hip_fail(_e, #call); \
+  } while (0)
+
+// ---- per-kernel HIP-event timing (finrom_profile_*) ------------------------------------
+enum KernelSlot {
+  K_PACK = 0,      // row-major [S x d] -> sample-blocked [S/64][d][64]
+  K_FOM,           // affine assembly + sparse Cholesky + two triangular solves + QoI
+  K_UNPACK_W,      // blocked w -> row-major, original dof order
+  K_ROM_PROJ,      // psi build + psi^T psi (fp64 MFMA) + psi^T F
+  K_ROM_SOLVE,     // dense Cholesky solve of the reduced system + QoI
+  K_AVG,           // theta = S k
+  K_SAMPLER,       // k = exp(0.5 U^T xi)
+  K_MISC,
+  K_NUM
+};
+struct ScopedKernelTimer {
+  int slot; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ScopedKernelTimer(int slot, hipStream_t s);
+  ~ScopedKernelTimer();
+};
+
+template <class T>
+int upload(T** dptr, const T* host, size_t count) {
+  *dptr = nullptr;
+  if (count == 0) return 0;
+  hipError_t e = hipMalloc((void**)dptr, count * sizeof(T));
+  if (e != hipSuccess) { set_error("hipMalloc failed (" + std::to_string(count * sizeof(T)) + " bytes)"); return FINROM_ERR_NOMEM; }
+  FR_HIP(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// grow-only device scratch buffer owned by a handle
+struct Scratch {
+  void* p = nullptr; size_t cap = 0;
+  int reserve(size_t bytes);
+  void release();
+};
+
+// ---- FOM ------------------------------------------------------------------------------
+struct FomDev {
+  int n, nnzL, npairs, xdim, n_obs;
+  const int* row_ptr; const int* ent_col; const int* pair_ptr; const int* pair_a; const int* pair_b;
+  const double* asm_c0; const int* asm_ptr; const int* asm_idx; const double* asm_w;
+  const double* rhs; const int* col_ptr; const int* col_ent; const int* col_row;
+  const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
+};
+int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st);
+int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Lw, double* invd,
+               double* yw, double* qoi, int* info, hipStream_t st);
+int launch_unpack_w(const FomDev& p, const double* yw, int64_t S, double* w, hipStream_t st);
+
+// ---- ROM ------------------------------------------------------------------------------
+struct RomDev {
+  int n, r, rp, NB, P, n_obs, nk;      // rp = 16*NB padded basis size, nk = k-steps of 4 rows
+  const int* kstep_ptr;                 // [nk+1] -> slots
+  const int2* slot;                     // [nslots*4] {offset of the r-vector in term_val (in doubles), theta index}
+  const double* term_val;               // padded rows of rp doubles; row 0 is all zeros
+  const double* rhs4;                   // [nk*4] F per psi row (0 for padding rows)
+  const double* obs_phi;                // [n_obs x r]
+};
+int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, hipStream_t st);
+int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r,
+                     double* qoi_r, double* Ar_out, double* Br_out, int* info, hipStream_t st);
+
+}  // namespace finrom

@@ -1,0 +1,167 @@
+// FOM side of the hot path: batched sparse SPD solve with a fixed symbolic factorisation.
+//
+// Replaces, for a whole batch, the per-sample DOLFIN calls of
+//   Fin.forward            fom/forward_solve.py:270-291  (assemble A(k), sparse direct solve)
+//   Fin.qoi_operator       fom/forward_solve.py:408-412  (B_obs @ w)
+//   AffineROMFin.forward   rom/averaged_affine_ROM.py:237-258 (same solve, affine operator)
+//
+// Mapping to the hardware: lane = sample.  All samples share the elimination schedule, so
+// control flow and every index are wave-uniform (SGPRs, scalar loads), and each vector
+// memory access is one fully coalesced 512-byte line: element e of the wave's 64 samples
+// lives at  base + e*64 + lane  ("sample-blocked" layout [S/64][elements][64]).
+// Bound: HBM/L2 bandwidth (2 loads of 8 B per multiply-add, no reuse in registers).
+#include "finrom_internal.h"
+
+namespace finrom {
+
+// ---------------------------------------------------------------------------------------
+// pack: row-major x[S][d] -> blocked xT[nblk][d][64]; tail samples replicate sample S-1
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(const double* __restrict__ x, int64_t S, int d,
+                                                   double* __restrict__ xT) {
+  __shared__ double tile[64][65];
+  const int64_t blk = blockIdx.x;
+  const int d0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int sl = ty; sl < 64; sl += 4) {           // read: dims fastest (coalesced along a row of x)
+    int64_t s = blk * 64 + sl;
+    if (s >= S) s = S - 1;
+    int j = d0 + tx;
+    tile[sl][tx] = (j < d) ? x[s * d + j] : 0.0;
+  }
+  __syncthreads();
+  for (int jl = ty; jl < 64; jl += 4) {           // write: samples fastest
+    int j = d0 + jl;
+    if (j < d) xT[(blk * d + j) * 64 + tx] = tile[tx][jl];
+  }
+}
+
+int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st) {
+  int64_t nblk = (S + 63) / 64;
+  if (nblk == 0) return 0;
+  ScopedKernelTimer t(K_PACK, st);
+  dim3 grid((unsigned)nblk, (unsigned)((d + 63) / 64));
+  hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 0, st, x, S, d, xT);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused FOM kernel, one wave per block of 64 samples
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restrict__ xT, int64_t S,
+                                                 double* __restrict__ Lw, double* __restrict__ invd,
+                                                 double* __restrict__ yw, double* __restrict__ qoi,
+                                                 int* __restrict__ info) {
+  const int lane = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  const double* xb = xT + blk * (int64_t)p.xdim * 64 + lane;
+  double* Lb = Lw + blk * (int64_t)p.nnzL * 64 + lane;
+  double* ib = invd + blk * (int64_t)p.n * 64 + lane;
+  double* yb = yw + blk * (int64_t)p.n * 64 + lane;
+  int bad = 0;
+
+  // ---- numeric factorisation A = L L^T, row by row, fused with  L y = F ---------------
+  for (int i = 0; i < p.n; ++i) {
+    const int e0 = p.row_ptr[i], e1 = p.row_ptr[i + 1];
+    double inv_i = 0.0;
+    for (int e = e0; e < e1; ++e) {
+      // affine assembly of A_e(x)            (fom :160-161 / rom :154-163)
+      double acc = p.asm_c0[e];
+      for (int t = p.asm_ptr[e], t1 = p.asm_ptr[e + 1]; t < t1; ++t)
+        acc = fma(p.asm_w[t], xb[(int64_t)p.asm_idx[t] * 64], acc);
+      // acc -= sum_k L_ik L_jk
+      int q = p.pair_ptr[e];
+      const int q1 = p.pair_ptr[e + 1];
+      for (; q + 4 <= q1; q += 4) {
+        const int a0 = p.pair_a[q], a1 = p.pair_a[q + 1], a2 = p.pair_a[q + 2], a3 = p.pair_a[q + 3];
+        const int b0 = p.pair_b[q], b1 = p.pair_b[q + 1], b2 = p.pair_b[q + 2], b3 = p.pair_b[q + 3];
+        const double la0 = Lb[(int64_t)a0 * 64], lb0 = Lb[(int64_t)b0 * 64];
+        const double la1 = Lb[(int64_t)a1 * 64], lb1 = Lb[(int64_t)b1 * 64];
+        const double la2 = Lb[(int64_t)a2 * 64], lb2 = Lb[(int64_t)b2 * 64];
+        const double la3 = Lb[(int64_t)a3 * 64], lb3 = Lb[(int64_t)b3 * 64];
+        acc = fma(-la0, lb0, acc); acc = fma(-la1, lb1, acc);
+        acc = fma(-la2, lb2, acc); acc = fma(-la3, lb3, acc);
+      }
+      for (; q < q1; ++q)
+        acc = fma(-Lb[(int64_t)p.pair_a[q] * 64], Lb[(int64_t)p.pair_b[q] * 64], acc);
+      if (e == e1 - 1) {                       // diagonal
+        bad |= !(acc > 0.0);
+        const double d = sqrt(acc);
+        inv_i = 1.0 / d;
+        Lb[(int64_t)e * 64] = d;
+        ib[(int64_t)i * 64] = inv_i;
+      } else {
+        Lb[(int64_t)e * 64] = acc * ib[(int64_t)p.ent_col[e] * 64];
+      }
+    }
+    double yi = p.rhs[i];
+    for (int e = e0; e < e1 - 1; ++e)
+      yi = fma(-Lb[(int64_t)e * 64], yb[(int64_t)p.ent_col[e] * 64], yi);
+    yb[(int64_t)i * 64] = yi * inv_i;
+  }
+
+  // ---- L^T w = y, in place (w overwrites y) -------------------------------------------
+  for (int i = p.n - 1; i >= 0; --i) {
+    double wi = yb[(int64_t)i * 64];
+    for (int c = p.col_ptr[i], c1 = p.col_ptr[i + 1]; c < c1; ++c)
+      wi = fma(-Lb[(int64_t)p.col_ent[c] * 64], yb[(int64_t)p.col_row[c] * 64], wi);
+    yb[(int64_t)i * 64] = wi * ib[(int64_t)i * 64];
+  }
+
+  // ---- QoI = B_obs w  (fom :408-412) ---------------------------------------------------
+  const int64_t s = blk * 64 + lane;
+  const double nanv = __builtin_nan("");
+  for (int o = 0; o < p.n_obs; ++o) {
+    double qv = 0.0;
+    for (int t = p.obs_ptr[o], t1 = p.obs_ptr[o + 1]; t < t1; ++t)
+      qv = fma(p.obs_w[t], yb[(int64_t)p.obs_idx[t] * 64], qv);
+    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : qv;
+  }
+  if (bad)
+    for (int i = 0; i < p.n; ++i) yb[(int64_t)i * 64] = nanv;
+  if (info != nullptr && s < S) info[s] |= bad ? 1 : 0;
+}
+
+int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Lw, double* invd,
+               double* yw, double* qoi, int* info, hipStream_t st) {
+  if (nblk == 0) return 0;
+  ScopedKernelTimer t(K_FOM, st);
+  hipLaunchKernelGGL(fom_kernel, dim3((unsigned)nblk), dim3(64), 0, st, p, xT, S, Lw, invd, yw, qoi, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// unpack: blocked, permuted w -> row-major w[S][n] in the caller's dof order
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unpack_w_kernel(const double* __restrict__ yw, const int* __restrict__ perm,
+                                                       int n, int64_t S, double* __restrict__ w) {
+  __shared__ double tile[64][65];
+  const int64_t blk = blockIdx.x;
+  const int i0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int il = ty; il < 64; il += 4) {
+    int i = i0 + il;
+    tile[il][tx] = (i < n) ? yw[(blk * n + i) * 64 + tx] : 0.0;
+  }
+  __syncthreads();
+  const int i = i0 + tx;
+  const int col = (i < n) ? perm[i] : 0;
+  for (int sl = ty; sl < 64; sl += 4) {
+    int64_t s = blk * 64 + sl;
+    if (s < S && i < n) w[s * n + col] = tile[tx][sl];
+  }
+}
+
+int launch_unpack_w(const FomDev& p, const double* yw, int64_t S, double* w, hipStream_t st) {
+  int64_t nblk = (S + 63) / 64;
+  if (nblk == 0) return 0;
+  ScopedKernelTimer t(K_UNPACK_W, st);
+  dim3 grid((unsigned)nblk, (unsigned)((p.n + 63) / 64));
+  hipLaunchKernelGGL(unpack_w_kernel, grid, dim3(256), 0, st, yw, p.perm, p.n, S, w);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace finrom

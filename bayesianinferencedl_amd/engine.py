@@ -1,0 +1,225 @@
+"""Python-side owners of the library handles.  Each ``solve`` is one C-ABI call that runs the
+whole batch on the GPU; inputs may be NumPy arrays (copied to / from the device around the
+call) or torch CUDA tensors (used in place, results returned as torch tensors on the same
+device, launched on torch's current stream)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _ffi
+from ._ffi import DeviceBuffer, FomDesc, RomDesc, check, f64, i32, lib
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class _Batch:
+    """Uniform view of a [S, d] fp64 batch living on the device."""
+
+    def __init__(self, x, d):
+        self.torch = _is_torch(x)
+        if self.torch:
+            import torch
+            if not x.is_cuda or x.dtype != torch.float64:
+                raise TypeError("torch inputs must be float64 CUDA tensors")
+            x = x.reshape(-1, d).contiguous()
+            self.keep = x
+            self.S = x.shape[0]
+            self.ptr = x.data_ptr()
+            self.device = x.device
+            self.stream = torch.cuda.current_stream(x.device).cuda_stream
+        else:
+            a = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, d)
+            self.S = a.shape[0]
+            self.keep = DeviceBuffer.from_numpy(a)
+            self.ptr = self.keep.ptr
+            self.stream = None
+
+    def new(self, shape, dtype="f8"):
+        """Allocate an output of the same kind; returns (object, device pointer)."""
+        if self.torch:
+            import torch
+            t = torch.zeros(shape, dtype=torch.float64 if dtype == "f8" else torch.int32, device=self.device)
+            return t, t.data_ptr()
+        n = int(np.prod(shape)) * (8 if dtype == "f8" else 4)
+        b = DeviceBuffer(n)
+        b.zero()
+        return b, b.ptr
+
+    def out(self, obj, shape, dtype="f8"):
+        if self.torch:
+            return obj
+        return obj.to_numpy(shape, np.float64 if dtype == "f8" else np.int32)
+
+
+def _csr_rows(M):
+    M = sp.csr_matrix(M)
+    M.sort_indices()
+    return M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)
+
+
+class FomEngine:
+    """Batched ``A(x) w = F`` + QoI (finrom_fom_*).  ``c0``/``W`` define the sparse-affine
+    value map on the CSR pattern of A (see include/finrom.h)."""
+
+    def __init__(self, plan, c0_csr, W_csr, rhs, B_obs):
+        self.plan = plan
+        self.n = plan.n
+        W_csr = sp.csr_matrix(W_csr)
+        self.xdim = W_csr.shape[1]
+        c0, aptr, aidx, aw = plan.entry_table(c0_csr, W_csr)
+        Bp = sp.csr_matrix(np.asarray(B_obs)[:, plan.perm]) if not sp.issparse(B_obs) else sp.csr_matrix(B_obs)[:, plan.perm]
+        optr, oidx, ow = _csr_rows(Bp)
+        self.n_obs = Bp.shape[0]
+        keep = []
+
+        def I(a):
+            a, p = i32(a); keep.append(a); return p
+
+        def D(a):
+            a, p = f64(a); keep.append(a); return p
+
+        d = FomDesc(n=plan.n, nnzL=plan.nnzL, npairs=plan.npairs, xdim=self.xdim, n_obs=self.n_obs, nasm=len(aidx),
+                    row_ptr=I(plan.row_ptr), ent_col=I(plan.ent_col), pair_ptr=I(plan.pair_ptr),
+                    pair_a=I(plan.pair_a), pair_b=I(plan.pair_b), asm_c0=D(c0), asm_ptr=I(aptr),
+                    asm_idx=I(aidx), asm_w=D(aw), rhs=D(np.asarray(rhs)[plan.perm]), col_ptr=I(plan.col_ptr),
+                    col_ent=I(plan.col_ent), col_row=I(plan.col_row), obs_ptr=I(optr), obs_idx=I(oidx),
+                    obs_w=D(ow), perm=I(plan.perm))
+        h = C.c_void_p()
+        check(lib().finrom_fom_create(C.byref(d), C.byref(h)), "finrom_fom_create")
+        self._h = h
+
+    def solve(self, X, want_w=False):
+        b = _Batch(X, self.xdim)
+        S = b.S
+        qoi, qp = b.new((S, self.n_obs))
+        info, ip = b.new((S,), "i4")
+        w, wp = (b.new((S, self.n)) if want_w else (None, None))
+        check(lib().finrom_fom_solve(self._h, b.ptr, S, qp, wp, ip, b.stream), "finrom_fom_solve")
+        return {"qoi": b.out(qoi, (S, self.n_obs)), "w": b.out(w, (S, self.n)) if want_w else None,
+                "info": b.out(info, (S,), "i4")}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().finrom_fom_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RomEngine:
+    """Batched LSPG reduced solve (finrom_rom_*).
+
+    ``terms``: list of (theta_index, sparse-or-dense [n, r] matrix Psi_p = A_p Phi); theta_index 0 is the
+    constant (Robin) term, 1..P the parameters.  Only the non-zero rows of each Psi_p are shipped."""
+
+    def __init__(self, n, r, P, terms, rhs, obs_phi):
+        self.n, self.r, self.P = n, r, P
+        rows = [[] for _ in range(n)]
+        for p, M in terms:
+            M = np.asarray(M)
+            nzr = np.nonzero(np.abs(M).sum(1))[0]
+            for j in nzr:
+                rows[j].append((p, M[j]))
+        row_ptr = np.zeros(n + 1, np.int32)
+        term_p, term_val = [], []
+        for j in range(n):
+            for p, v in rows[j]:
+                term_p.append(p); term_val.append(v)
+            row_ptr[j + 1] = len(term_p)
+        self.nterms = len(term_p)
+        tv = np.asarray(term_val, dtype=np.float64).reshape(self.nterms, r)
+        obs_phi = np.ascontiguousarray(obs_phi, dtype=np.float64)
+        self.n_obs = obs_phi.shape[0]
+        a1, p1 = i32(row_ptr); a2, p2 = i32(term_p); a3, p3 = f64(tv); a4, p4 = f64(rhs); a5, p5 = f64(obs_phi)
+        d = RomDesc(n=n, r=r, P=P, n_obs=self.n_obs, nterms=self.nterms, row_ptr=p1, term_p=p2, term_val=p3,
+                    rhs=p4, obs_phi=p5)
+        h = C.c_void_p()
+        check(lib().finrom_rom_create(C.byref(d), C.byref(h)), "finrom_rom_create")
+        self._h = h
+
+    def solve(self, theta, want_state=False):
+        b = _Batch(theta, self.P)
+        S, r = b.S, self.r
+        w_r, wp = b.new((S, r))
+        qoi, qp = b.new((S, self.n_obs))
+        info, ip = b.new((S,), "i4")
+        A_r, Ap = (b.new((S, r, r)) if want_state else (None, None))
+        B_r, Bp = (b.new((S, r)) if want_state else (None, None))
+        check(lib().finrom_rom_solve(self._h, b.ptr, S, wp, qp, Ap, Bp, ip, b.stream), "finrom_rom_solve")
+        out = {"w_r": b.out(w_r, (S, r)), "qoi_r": b.out(qoi, (S, self.n_obs)), "info": b.out(info, (S,), "i4")}
+        if want_state:
+            out["A_r"] = b.out(A_r, (S, r, r)); out["B_r"] = b.out(B_r, (S, r))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().finrom_rom_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SubfinAverager:
+    """theta = S k on the device (finrom_subfin_avg)."""
+
+    def __init__(self, Sop):
+        Sop = np.ascontiguousarray(Sop, dtype=np.float64)
+        self.P, self.n = Sop.shape
+        self._S = DeviceBuffer.from_numpy(Sop)
+
+    def __call__(self, K):
+        b = _Batch(K, self.n)
+        th, tp = b.new((b.S, self.P))
+        check(lib().finrom_subfin_avg(self._S.ptr, self.P, self.n, b.ptr, b.S, tp, b.stream), "finrom_subfin_avg")
+        return b.out(th, (b.S, self.P))
+
+
+class FieldSampler:
+    """k = exp(0.5 * xi @ U) on the device (finrom_sampler_*)."""
+
+    def __init__(self, U):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        self.n = U.shape[0]
+        h = C.c_void_p()
+        check(lib().finrom_sampler_create(U.ctypes.data_as(_ffi.c_f64p), self.n, C.byref(h)), "finrom_sampler_create")
+        self._h = h
+
+    def __call__(self, xi):
+        b = _Batch(xi, self.n)
+        k, kp = b.new((b.S, self.n))
+        check(lib().finrom_sampler_draw(self._h, b.ptr, b.S, kp, b.stream), "finrom_sampler_draw")
+        return b.out(k, (b.S, self.n))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().finrom_sampler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_sub(a, b_):
+    """a - b elementwise on the device (generate_fin_dataset.py:99)."""
+    ba = _Batch(a, 1)
+    bb = _Batch(b_, 1)
+    out, op = ba.new((ba.S,))
+    check(lib().finrom_sub(ba.ptr, bb.ptr, ba.S, op, ba.stream), "finrom_sub")
+    res = ba.out(out, (ba.S,))
+    return res.reshape(a.shape)

@@ -1,0 +1,134 @@
+"""MI355X-native ``Fin``: the full-order thermal-fin solver behind the reference's call
+surface (fom/forward_solve.py::Fin).  Every solve goes through libfinrom_hip.so; scalar
+methods are batches of one.
+
+Reference methods mirrored (file fom/forward_solve.py): __init__ :98-265 (hot-path subset),
+forward :270-291, forward_five_param :267-268, qoi_operator :408-412, reduced_qoi_operator
+:415-419, reduced_forward :421-452, r_fwd_no_full :454-464, subfin_avg_op :466-480,
+nine_param_to_function :482-486, observation_operator :488-511.  five_param_to_function
+follows the only surviving definition, fom/forward_solve_petsc.py:243-260."""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+from ..fem import BIOT, Function, FunctionSpace, as_nodal
+from ..symbolic import CholeskyPlan
+from ..engine import FomEngine, SubfinAverager
+
+
+def _plan_for(V: FunctionSpace) -> CholeskyPlan:
+    if getattr(V, "_chol_plan", None) is None:
+        ops = V.operators()
+        V._chol_plan = CholeskyPlan(ops.indptr, ops.indices, ops.n)
+    return V._chol_plan
+
+
+def external_observation_matrix(ops, n_obs=40, seed=32):
+    """fom/forward_solve.py:215-228.  ``rand_boundary_indices.npy`` is not in the reference
+    repository; its commented recipe is ``np.random.seed(32); np.random.choice(boundary, 40)``."""
+    rs = np.random.RandomState(seed)
+    b_vals = rs.choice(np.unique(ops.mesh.robin_facets), n_obs)
+    B = np.zeros((n_obs, ops.n))
+    B[np.arange(n_obs), b_vals] = 1
+    return B
+
+
+class Fin:
+    """Heat conduction in the thermal fin, full-order model, batched on the GPU."""
+
+    def __init__(self, V, external_obs=False):
+        self.phi = None
+        self.V = V
+        self.dofs = len(V.dofmap().dofs())
+        self.Bi = BIOT
+        self.ops = ops = V.operators()
+        self._k = Function(V)
+        self.B = ops.F.copy()                                  # :163
+        self.fin_areas = ops.areas                             # :205-213
+        self.domain_measure = float(ops.cell_area.sum())
+        self.C = ops.S.T @ ops.areas / self.domain_measure     # averaging_operator :396-406
+        if external_obs:
+            self.n_obs = 40
+            self.B_obs = external_observation_matrix(ops, self.n_obs)
+        else:
+            self.n_obs = 9
+            self.B_obs = self.observation_operator()           # :229-231
+        self._plan = _plan_for(V)
+        self._engines = {}
+        self._avg = None
+
+    # ---- engines (created lazily; each owns a device copy of its operator table) --------
+    def _engine(self, kind):
+        if kind not in self._engines:
+            ops = self.ops
+            if kind == "field":        # x = nodal conductivity, A = int k grad w.grad v + Bi int w v
+                W = ops.W_field
+            elif kind == "nine":       # x = 9 fin conductivities through nine_param_to_function
+                W = sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9))
+            elif kind == "five":
+                W = sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9 @ ops.E59))
+            else:
+                raise KeyError(kind)
+            self._engines[kind] = FomEngine(self._plan, ops.robin_vals, W, ops.F, self.B_obs)
+        return self._engines[kind]
+
+    # ---- batched extensions (new, additive) ---------------------------------------------
+    def forward_batch(self, K, want_w=True, params=None):
+        """K [S, n] nodal fields (or [S, 9] / [S, 5] fin conductivities with params='nine'/'five')
+        -> dict(qoi [S, n_obs], w [S, n] | None, info [S])."""
+        return self._engine(params or "field").solve(K, want_w=want_w)
+
+    def subfin_avg_batch(self, K):
+        if self._avg is None:
+            self._avg = SubfinAverager(self.ops.S)
+        return self._avg(K)
+
+    # ---- reference call surface -------------------------------------------------------------
+    def forward(self, k):
+        self._k.assign(k)
+        res = self._engine("field").solve(as_nodal(self._k)[None, :], want_w=True)
+        if res["info"][0]:
+            raise np.linalg.LinAlgError("FOM operator not positive definite for this conductivity")
+        z = Function(self.V, res["w"][0])
+        z._qoi = res["qoi"][0].copy()
+        return z, None, None, None, None
+
+    def forward_five_param(self, k_s):
+        return self.forward(self.five_param_to_function(k_s))
+
+    def five_param_to_function(self, k_s):
+        return Function(self.V, self.ops.N9 @ (self.ops.E59 @ np.asarray(k_s, float)))
+
+    def nine_param_to_function(self, k_s):
+        return Function(self.V, self.ops.N9 @ np.asarray(k_s, float))
+
+    def qoi_operator(self, x):
+        q = getattr(x, "_qoi", None)
+        if q is not None and q.shape[0] == self.n_obs:
+            return q.copy()                                    # computed by the solve kernel
+        return np.dot(self.B_obs, as_nodal(x))
+
+    def reduced_qoi_operator(self, z_r):
+        return np.dot(self.B_obs, np.dot(self.phi, z_r))
+
+    def subfin_avg_op(self, k):
+        return np.asarray(self.subfin_avg_batch(as_nodal(k)[None, :]))[0]
+
+    def observation_operator(self):
+        return self.ops.S.copy()
+
+    def reduced_forward(self, A, B, C, psi, phi):
+        """Dense LSPG on explicit host matrices (:421-452): (A_r, B_r, C_r, x_r, y_r).  Its
+        arguments ARE dense NumPy matrices; the batched device path is AffineROMFin."""
+        self.phi = phi
+        A_r = psi.T @ (A @ phi)
+        B_r = psi.T @ B
+        C_r = C @ phi
+        x_r = np.linalg.solve(A_r, B_r)
+        return A_r, B_r, C_r, x_r, C_r @ x_r
+
+    def r_fwd_no_full(self, k, phi):
+        self._k.assign(k)
+        A_m = self.ops.csr(self.ops.fom_values(as_nodal(self._k))).toarray()
+        return self.reduced_forward(A_m, self.B, self.C, A_m @ phi, phi)

@@ -1,0 +1,138 @@
+"""MI355X-native ``AffineROMFin``: the sub-fin-averaged affine reduced-order model behind
+the reference's call surface (rom/averaged_affine_ROM.py::AffineROMFin).
+
+Reference methods mirrored (file rom/averaged_affine_ROM.py): __init__ :57-235 (forward-path
+subset), forward :237-258, forward_reduced :260-276, forward_nine_param_reduced :278-310,
+qoi :312-320, qoi_reduced :323-333, set_data/set_dl_model :398-402, subfin_avg_op :404-418,
+observation_operator :420-445.  The reduced system is least-squares Petrov-Galerkin
+(psi = A Phi, A_r = psi^T psi, :295-297), NOT Galerkin."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+from ..fem import BIOT, Function, as_nodal
+from ..engine import FomEngine, RomEngine, SubfinAverager
+from ..fom.forward_solve import _plan_for, external_observation_matrix
+
+
+class AffineROMFin:
+    def __init__(self, V, err_model, phi, external_obs=False):
+        self.fwd_time = 0.0
+        self.rom_grad_time = 0.0
+        self.romml_grad_time = 0.0
+        self.romml_grad_time_dl = 0.0
+        self.num_params = 9
+        self.phi = np.ascontiguousarray(phi, dtype=np.float64)
+        (self.n, self.n_r) = self.phi.shape
+        self.V = V
+        self.dofs = len(V.dofmap().dofs())
+        if self.n != self.dofs:
+            raise ValueError(f"basis has {self.n} rows but the space has {self.dofs} dofs")
+        self.Bi = BIOT
+        self.ops = ops = V.operators()
+        self.B = ops.F.copy()                                   # :171,178
+        if external_obs:
+            self.n_obs = 40
+            self.B_obs = external_observation_matrix(ops, self.n_obs)
+        else:
+            self.n_obs = 9
+            self.B_obs = self.observation_operator()
+        self.dsigma_dk = self.observation_operator()            # :210
+        self.B_obs_phi = np.dot(self.B_obs, self.phi)           # :212
+        # :215-220  Psi_i = A_i Phi (the reference also stores the dense 9 x n x n A_i: 150 MB
+        # at n = 1446; kept sparse here -- see .dA_dsigmak)
+        self._A_sub = [ops.csr(ops.sub_vals[i]) for i in range(9)]
+        self.dA_dsigmak_phi = np.stack([A @ self.phi for A in self._A_sub])
+        self.dl_model = err_model
+        self.data = None
+        self.psi = None
+        self._A_r = None
+        self._B_r = None
+        robin_phi = ops.csr(ops.robin_vals) @ self.phi
+        terms = [(0, robin_phi)] + [(i + 1, self.dA_dsigmak_phi[i]) for i in range(9)]
+        self._rom = RomEngine(self.n, self.n_r, 9, terms, ops.F, self.B_obs_phi)
+        self._avg = SubfinAverager(ops.S)
+        self._plan = _plan_for(V)
+        self._fom = None
+
+    @property
+    def dA_dsigmak(self):
+        """Dense [9, n, n] stack as in the reference (:215-218); materialised on demand."""
+        return np.stack([A.toarray() for A in self._A_sub])
+
+    # ---- batched extensions (new, additive) ---------------------------------------------
+    def subfin_avg_batch(self, K):
+        return self._avg(K)
+
+    def forward_nine_param_reduced_batch(self, theta, want_state=False):
+        """theta [S, 9] -> dict(w_r [S, r], qoi_r [S, n_obs], info [S] (, A_r, B_r))."""
+        return self._rom.solve(theta, want_state=want_state)
+
+    def forward_reduced_batch(self, K, want_state=False):
+        """K [S, n] nodal fields -> theta = S k on the device -> reduced solve."""
+        return self._rom.solve(self._avg(K), want_state=want_state)
+
+    def forward_batch(self, K, want_w=True):
+        """'Averaged FOM' (:237-258) for a batch of nodal fields."""
+        if self._fom is None:
+            ops = self.ops
+            self._fom = FomEngine(self._plan, ops.robin_vals, sp.csr_matrix(ops.sub_vals.T), ops.F, self.B_obs)
+        return self._fom.solve(self._avg(K), want_w=want_w)
+
+    # ---- reference call surface -------------------------------------------------------------
+    def forward(self, k):
+        res = self.forward_batch(as_nodal(k)[None, :])
+        if res["info"][0]:
+            raise np.linalg.LinAlgError("averaged operator not positive definite")
+        w = Function(self.V, res["w"][0])
+        w._qoi = res["qoi"][0].copy()
+        return w
+
+    def forward_reduced(self, k):
+        t_i = time.time()
+        k_s = self.subfin_avg_op(k)
+        self.fwd_time += (time.time() - t_i)
+        return self.forward_nine_param_reduced(k_s)
+
+    def forward_nine_param_reduced(self, k_s):
+        t_i = time.time()
+        res = self._rom.solve(np.asarray(k_s, dtype=np.float64)[None, :], want_state=True)
+        self.fwd_time += (time.time() - t_i)
+        if res["info"][0]:
+            raise np.linalg.LinAlgError("reduced operator not positive definite")
+        self._A_r, self._B_r = res["A_r"][0], res["B_r"][0]     # state the gradients use (:342-343)
+        self._theta = np.asarray(k_s, dtype=np.float64).copy()
+        w_r = res["w_r"][0]
+        self._last = (w_r.copy(), res["qoi_r"][0].copy())
+        return w_r
+
+    def qoi(self, w):
+        q = getattr(w, "_qoi", None)
+        if q is not None and q.shape[0] == self.n_obs:
+            return q.copy()
+        return np.dot(self.B_obs, as_nodal(w))
+
+    def qoi_reduced(self, w_r):
+        t_i = time.time()
+        last = getattr(self, "_last", None)
+        if last is not None and w_r.shape == last[0].shape and np.array_equal(w_r, last[0]):
+            qoi_vals = last[1].copy()                           # computed by the solve kernel
+        else:
+            qoi_vals = np.dot(self.B_obs_phi, w_r)
+        self.fwd_time += (time.time() - t_i)
+        return qoi_vals
+
+    def set_data(self, data):
+        self.data = data
+
+    def set_dl_model(self, model):
+        self.dl_model = model
+
+    def subfin_avg_op(self, k):
+        return np.asarray(self._avg(as_nodal(k)[None, :]))[0]
+
+    def observation_operator(self):
+        return self.ops.S.copy()

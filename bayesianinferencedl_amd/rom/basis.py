@@ -1,0 +1,32 @@
+"""Reduced bases for the fin.  The reference ships bases tied to its irreproducible mshr
+mesh (data/basis_*_param.txt, 1446 x 81), so a basis for OUR mesh is built
+with the reference's POD recipe (rom/generate_reduced_basis_nine_param.py:296-318:
+snapshots of the FOM for k ~ U(0.1, 3.5)^9) using the batched device FOM, then
+orthonormalised (parity on raw w_r needs orthonormal columns)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def pod_basis(solver, r, n_snapshots=400, low=0.1, high=3.5, params="nine", seed=1):
+    rng = np.random.default_rng(seed)
+    dim = {"nine": 9, "five": 5}[params]
+    kappa = rng.uniform(low, high, size=(n_snapshots, dim))
+    Y = np.asarray(solver.forward_batch(kappa, want_w=True, params=params)["w"])   # batched device FOM
+    _, _, Vt = np.linalg.svd(Y, full_matrices=False)                              # one-time host setup
+    return np.ascontiguousarray(Vt[:r].T)
+
+
+def load_basis_csv(path):
+    """Reader for the reference's basis format: np.savetxt(..., delimiter=',')."""
+    return np.loadtxt(path, delimiter=",")
+
+
+def load_or_build_basis(V, solver, path=None, r=81):
+    if path is not None and os.path.exists(path):
+        phi = load_basis_csv(path)
+        if phi.shape[0] == V.dim():
+            return phi
+    return pod_basis(solver, r)

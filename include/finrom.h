@@ -1,0 +1,166 @@
+/*
+ * finrom.h -- C ABI of libfinrom_hip.so: the MI355X (gfx950) implementation of the
+ * thermal-fin FOM + ROM forward-solve hot path of sheroze1123/BayesianInferenceDL.
+ *
+ * The reference has no FFI of its own (pure Python); its boundary is the
+ * Python class surface.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference repository).  The Python mirror of those classes
+ * (bayesianinferencedl_amd/fom/forward_solve.py, rom/averaged_affine_ROM.py, ...) binds
+ * these symbols through ctypes (bayesianinferencedl_amd/_ffi.py); see INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain pointers and sizes, no C++ / torch types; all arithmetic is IEEE fp64;
+ *  - every function returns 0 on success or a negative finrom_status; it never throws
+ *    or aborts; finrom_last_error() gives the thread-local message of the last failure;
+ *  - descriptor arrays are HOST pointers, borrowed for the duration of the create call
+ *    and copied to the device; the handle owns all device memory it allocates;
+ *  - batch arrays (x, theta, qoi, w, ...) are DEVICE pointers, row-major [S x dim],
+ *    caller-allocated (finrom_malloc or any other HIP allocator, e.g. a torch tensor);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are
+ *    asynchronous on that stream unless stated; a handle is used by one host thread at
+ *    a time (the reference classes are not re-entrant either).
+ *  - info[s] != 0 marks a failed sample (bit 0: FOM pivot <= 0 or NaN, bit 1: ROM pivot);
+ *    its outputs are NaN.
+ */
+#ifndef FINROM_H
+#define FINROM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FINROM_ABI_VERSION 1
+
+typedef enum {
+  FINROM_OK = 0,
+  FINROM_ERR_ARG = -1,      /* bad argument / inconsistent descriptor */
+  FINROM_ERR_HIP = -2,      /* a HIP runtime call failed (message has the hipError name) */
+  FINROM_ERR_NOMEM = -3,    /* device allocation failed */
+  FINROM_ERR_UNSUPPORTED = -4
+} finrom_status;
+
+typedef struct finrom_fom_s* finrom_fom_t;
+typedef struct finrom_rom_s* finrom_rom_t;
+typedef struct finrom_sampler_s* finrom_sampler_t;
+
+int finrom_version(void);
+const char* finrom_last_error(void);
+
+/* ---- device plumbing (so that callers need no other HIP binding) -------------------- */
+int finrom_device_count(int* count);
+int finrom_set_device(int ordinal);
+int finrom_malloc(void** dptr, size_t bytes);
+int finrom_free(void* dptr);
+int finrom_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int finrom_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int finrom_memset(void* dst, int value, size_t bytes, void* stream);
+int finrom_stream_sync(void* stream);
+
+/* ---- per-kernel timing with HIP events on the launch stream ------------------------- *
+ * When enabled every kernel launch of the library is bracketed by hipEventRecord on its
+ * stream; finrom_profile_read synchronises and returns, for kernel slot `slot`
+ * (0 <= slot < finrom_profile_slots()), its name, launch count and total milliseconds. */
+int finrom_profile_enable(int on);
+int finrom_profile_reset(void);
+int finrom_profile_slots(void);
+int finrom_profile_read(int slot, const char** name, int64_t* launches, double* total_ms);
+
+/* ---- FOM: batched sparse SPD solve  A(x) w = F  +  QoI ------------------------------ *
+ * Replaces Fin.forward + Fin.qoi_operator   (fom/forward_solve.py:270-291, 408-412),
+ * and AffineROMFin.forward + .qoi           (rom/averaged_affine_ROM.py:237-258, 312-320)
+ * for S samples at once.  The operator is a sparse-affine map on the entries of the
+ * Cholesky factor's pattern:  A_e(x) = asm_c0[e] + sum_t asm_w[t] * x[asm_idx[t]],
+ * t in [asm_ptr[e], asm_ptr[e+1]), which covers all three reference operators:
+ *   x = nodal field k (xdim = n)       int k_h grad w.grad v dx + Bi int w v ds   fom :160-161
+ *   x = 9 / 5 fin conductivities       same, through nine_param_to_function        fom :61-91
+ *   x = 9 sub-fin averages             sum_i x_i A_i + Bi M                        rom :154-163
+ * The symbolic phase (ordering, pattern of L, elimination schedule) is done once on the
+ * host (bayesianinferencedl_amd/symbolic.py); all arrays are in the PERMUTED dof order.
+ */
+typedef struct {
+  int32_t n;               /* dofs */
+  int32_t nnzL;            /* entries of L, row-major, diagonal last in each row */
+  int32_t npairs;          /* multiply-adds of the factorisation schedule */
+  int32_t xdim;            /* length of one parameter vector x */
+  int32_t n_obs;           /* rows of the observation operator */
+  int32_t nasm;            /* entries of asm_idx / asm_w */
+  const int32_t* row_ptr;  /* [n+1]  */
+  const int32_t* ent_col;  /* [nnzL] */
+  const int32_t* pair_ptr; /* [nnzL+1] */
+  const int32_t* pair_a;   /* [npairs] */
+  const int32_t* pair_b;   /* [npairs] */
+  const double*  asm_c0;   /* [nnzL] */
+  const int32_t* asm_ptr;  /* [nnzL+1] */
+  const int32_t* asm_idx;  /* [nasm] */
+  const double*  asm_w;    /* [nasm] */
+  const double*  rhs;      /* [n]   load vector F (fom :162-163), permuted */
+  const int32_t* col_ptr;  /* [n+1]  strictly-lower entries of each column of L */
+  const int32_t* col_ent;  /* [nnzL-n] */
+  const int32_t* col_row;  /* [nnzL-n] */
+  const int32_t* obs_ptr;  /* [n_obs+1]  CSR of B_obs (fom :215-231) over permuted dofs */
+  const int32_t* obs_idx;
+  const double*  obs_w;
+  const int32_t* perm;     /* [n] permuted -> original dof (to return w in caller order) */
+} finrom_fom_desc;
+
+int finrom_fom_create(const finrom_fom_desc* desc, finrom_fom_t* out);
+void finrom_fom_destroy(finrom_fom_t h);
+/* x [S x xdim] -> qoi [S x n_obs], optional w [S x n] (NULL to skip), info [S] (NULL ok) */
+int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S,
+                     double* qoi, double* w, int32_t* info, void* stream);
+
+/* ---- ROM: batched LSPG reduced solve ------------------------------------------------- *
+ * Replaces AffineROMFin.forward_nine_param_reduced + .qoi_reduced
+ * (rom/averaged_affine_ROM.py:278-310, 323-333):
+ *   psi = (sum_p theta_p A_p + Bi M) Phi ; A_r = psi^T psi ; B_r = psi^T F ;
+ *   w_r = A_r^{-1} B_r ; qoi_r = (B_obs Phi) w_r.
+ * The host passes the row-sparse tables Psi_p = A_p Phi (the reference's precomputed
+ * `dA_dsigmak_phi`, :215-220) as one list of r-vectors ("terms"): row j of psi is
+ *   sum_{t in [row_ptr[j], row_ptr[j+1])} theta[term_p[t]] * term_val[t][:]
+ * with theta[0] == 1 for the constant Robin term and theta[1..P] the parameters.
+ */
+typedef struct {
+  int32_t n;               /* rows of psi (dofs; any order) */
+  int32_t r;               /* basis size */
+  int32_t P;               /* number of parameters (theta has P entries per sample) */
+  int32_t n_obs;
+  int32_t nterms;
+  const int32_t* row_ptr;  /* [n+1] */
+  const int32_t* term_p;   /* [nterms] 0 = constant, 1..P = parameter index + 1 */
+  const double*  term_val; /* [nterms x r] row-major */
+  const double*  rhs;      /* [n]  F in the same row order */
+  const double*  obs_phi;  /* [n_obs x r] B_obs Phi (rom :212) */
+} finrom_rom_desc;
+
+int finrom_rom_create(const finrom_rom_desc* desc, finrom_rom_t* out);
+void finrom_rom_destroy(finrom_rom_t h);
+/* theta [S x P] -> w_r [S x r] (NULL to skip), qoi_r [S x n_obs], info [S] (NULL ok);
+ * optional A_r [S x r x r] and B_r [S x r] (the state the reference keeps in
+ * self._A_r / self._B_r for its gradients, :296-297) -- NULL to skip. */
+int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S,
+                     double* w_r, double* qoi_r, double* A_r, double* B_r,
+                     int32_t* info, void* stream);
+
+/* ---- sub-fin averages  theta = S k  (fom :466-480, rom :404-418) -------------------- *
+ * Sop is the dense [P x n] averaging operator on the device (finrom_malloc + h2d). */
+int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n,
+                      const double* k, int64_t S, double* theta, void* stream);
+
+/* ---- Gaussian-field sampler  k = exp(0.5 * U^T xi) ----------------------------------- *
+ * (deep_learning/generate_fin_dataset.py:87-88 with U = make_cov_chol(...),
+ *  bayesian_inference/gaussian_field.py:9-31; U is the UPPER factor, row-major [n x n],
+ *  host pointer copied at create).  xi [S x n] -> k [S x n]. */
+int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out);
+void finrom_sampler_destroy(finrom_sampler_t h);
+int finrom_sampler_draw(finrom_sampler_t h, const double* xi, int64_t S, double* k, void* stream);
+
+/* ---- elementwise helper: err = qoi - qoi_r (generate_fin_dataset.py:99) -------------- */
+int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FINROM_H */
