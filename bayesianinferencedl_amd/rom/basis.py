@@ -30,3 +30,15 @@ def load_or_build_basis(V, solver, path=None, r=81):
         if phi.shape[0] == V.dim():
             return phi
     return pod_basis(solver, r)
+
+
+def enrich(basis, w):
+    """Gram-Schmidt enrichment of a basis with one snapshot, as the reference's greedy sampler
+    does it (rom/model_constr_adaptive_sampling.py:50-68): note its loop stops at column k-2
+    (``range(0, k-1)``), i.e. the last existing column is NOT projected out; kept as is."""
+    U = np.hstack((np.asarray(basis, float), np.asarray(w, float).reshape(-1, 1)))
+    k = basis.shape[1]
+    for j in range(k - 1):
+        U[:, -1] -= (U[:, -1] @ U[:, j]) / (U[:, j] @ U[:, j]) * U[:, j]
+    U[:, -1] /= np.sqrt(U[:, -1] @ U[:, -1])
+    return U

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- FOM+ROM forward-solve sample pairs / second on MI355X (BASELINE.json metric).
+
+A *step* is one pass of the hot path (the body of deep_learning/generate_fin_dataset.py:83-100,
+batched) over one batch of synthetic conductivity samples already resident in HBM:
+    FOM sparse solve + QoI  ->  sub-fin averages  ->  LSPG ROM solve + QoI  ->  error.
+Workload (BASELINE.json configs[1]): five-parameter fin, lattice mesh m=12 (n = 1597 DoF),
+orthonormal POD basis r = 80, 100 000 samples per GPU, fp64.  With --gpus N > 1 every rank
+runs its own 100k-sample shard (weak scaling, no data-path collective) and the QoIs are
+gathered on rank 0 with one RCCL all_gather per step (the "gather at the end" of north_star).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel, measured live with HIP events on the launch stream
+  cpu_baseline  the NumPy/SciPy oracle (oracle/fin_oracle.py, kind="port") timed on one host core
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (vendor; = 256 CU * 4 SIMD * 32 FLOP/clk * 2.4 GHz)
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=100_000, help="samples per GPU per step")
+    ap.add_argument("--m", type=int, default=12, help="lattice divisor (12 -> 1597 DoF)")
+    ap.add_argument("--r", type=int, default=80)
+    ap.add_argument("--params", default="five", choices=["five", "nine", "field"])
+    ap.add_argument("--cpu-samples", type=int, default=2000, help="oracle samples for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def flops_per_pair(ops, plan, rom, n_obs, P):
+    """SURVEY 8(d) formula, direct LSPG with the symmetric half of psi^T psi."""
+    n, r = ops.n, rom.n_r
+    cc = np.diff(plan.col_ptr).astype(np.int64) + 1
+    return {
+        "assembly": 2 * (P + 1) * ops.nnz,
+        "cholesky": int((cc * cc).sum()),
+        "trisolves": 4 * plan.nnzL,
+        "psi": 2 * ops.nnz * r,
+        "syrk_sym": n * r * (r + 1),
+        "rhs": 2 * n * r,
+        "reduced_solve": r ** 3 // 3 + 2 * r * r,
+        "qoi": 2 * n_obs * (n + r),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bayesianinferencedl_amd import _ffi
+    from bayesianinferencedl_amd.fom.thermal_fin import get_space
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    from bayesianinferencedl_amd.rom.basis import pod_basis
+    from bayesianinferencedl_amd.pairs import FinPairSolver
+    _ffi.check(_ffi.lib().finrom_set_device(local_rank))
+
+    V = get_space(None, m=args.m)
+    solver = Fin(V)
+    bparams = "five" if args.params == "five" else "nine"
+    phi = pod_basis(solver, args.r, n_snapshots=400, low=0.1, high=10.0, params=bparams, seed=1)
+    solver_r = AffineROMFin(V, None, phi)
+    pairs = FinPairSolver(V, phi, False, args.params, solver, solver_r)
+
+    S = args.samples
+    # inputs are keyed by the GLOBAL sample index, so rank g's shard is rows [g*S, (g+1)*S) of
+    # the same stream whatever the GPU count (results independent of G)
+    rng = np.random.default_rng(3)
+    if args.params == "field":
+        from bayesianinferencedl_amd.bayesian_inference.gaussian_field import make_cov_chol
+        from bayesianinferencedl_amd.engine import FieldSampler
+        rng = np.random.default_rng(3 + rank)
+        xi = torch.from_numpy(rng.standard_normal((S, V.dim()))).to(dev)
+        X = FieldSampler(make_cov_chol(V, length=1.6))(xi)
+        del xi
+    else:
+        Xg = rng.uniform(0.1, 10.0, (world * S, pairs.xdim))
+        X = torch.from_numpy(Xg[rank * S:(rank + 1) * S]).to(dev)
+        del Xg
+    from bayesianinferencedl_amd.distributed import gather_rows
+
+    def step():
+        res = pairs.solve_pairs(X)
+        if world > 1:   # the one exchange step: QoI pairs of every shard (RCCL all_gather over xGMI)
+            res["gathered"] = gather_rows(torch.cat([res["qoi"], res["qoi_r"]], dim=1), world)
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    L = _ffi.lib()
+    L.finrom_profile_reset()
+    L.finrom_profile_enable(0 if args.no_profile else 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    L.finrom_profile_enable(0)
+    prof = _ffi.profile_read()
+    n_bad = int((res["info"] != 0).sum().item())
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ops, plan = V.operators(), solver._plan
+        fl = flops_per_pair(ops, plan, solver_r, pairs.n_obs, pairs.xdim)
+        total_pairs = world * S * args.steps
+        ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in prof.items()}       # avg ms per launch
+        # dominant kernel by measured time
+        cand = {k: v[1] for k, v in prof.items()}
+        dom = max(cand, key=cand.get) if any(cand.values()) else "rom_proj_mfma"
+        roof = None
+        if dom == "rom_proj_mfma" and ms[dom] > 0:
+            alg = S * (fl["syrk_sym"] + 2 * solver_r._rom.nterms * args.r + fl["rhs"])
+            ach = alg / (ms[dom] * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                    "algorithmic_flops_per_launch": alg, "avg_launch_ms": ms[dom]}
+        elif ms.get(dom, 0) > 0:
+            # FOM kernel: the factor is streamed (written once, read once by the back substitution)
+            alg = S * 8 * (2 * plan.nnzL + 4 * ops.n + pairs.xdim + pairs.n_obs)
+            ach = alg / (ms[dom] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms[dom]}
+
+        cpu = None
+        if world == 1 and args.cpu_samples > 0:
+            cpu = cpu_baseline(args, phi, X[: args.cpu_samples].cpu().numpy(), res, pairs)
+
+        out = {
+            "metric": "FOM+ROM forward-solve sample pairs/sec (five-param fin)",
+            "value": total_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.params}_param thermal fin, lattice m={args.m} (n={ops.n} DoF, nnz={ops.nnz}, "
+                                   f"nnz(L)={plan.nnzL}), POD basis r={args.r}, {S} samples per GPU, "
+                                   "FOM sparse Cholesky + LSPG ROM + QoIs + error per sample",
+                       "samples_per_gpu": S, "n_dof": ops.n, "r": args.r, "params": args.params,
+                       "flops_per_pair": int(sum(fl.values())), "failed_samples": n_bad},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, phi, Xs, res, pairs):
+    """The oracle's one-sample-at-a-time loop (what the reference does, minus FEniCS form
+    assembly overhead) on ONE host core, on the first `cpu_samples` inputs of the GPU batch."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:
+        limiter = None
+    from oracle import fin_oracle as O
+    prob = O.FinProblem(args.m)
+    fo = O.FinOracle(prob)
+    ro = O.AffineROMOracle(prob, phi)
+    lift = {"five": fo.five_param_to_function, "nine": fo.nine_param_to_function, "field": lambda x: x}[args.params]
+    budget_s = 25.0
+    t0 = time.perf_counter()
+    done = 0
+    q = np.zeros((len(Xs), 9)); qr = np.zeros((len(Xs), 9))
+    for i in range(len(Xs)):
+        k = lift(Xs[i])
+        w = fo.forward(k)
+        w_r = ro.forward_reduced(k)
+        q[i] = fo.qoi_operator(w); qr[i] = ro.qoi_reduced(w_r)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
+    gq = res["qoi"][:done].cpu().numpy(); gqr = res["qoi_r"][:done].cpu().numpy()
+    dev = float(max(np.max(np.linalg.norm(gq - q[:done], axis=1) / np.linalg.norm(q[:done], axis=1)),
+                    np.max(np.linalg.norm(gqr - qr[:done], axis=1) / np.linalg.norm(qr[:done], axis=1))))
+    return {"value": done / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} samples of the GPU batch, oracle/fin_oracle.py loop (SciPy SuperLU FOM + NumPy LSPG ROM), "
+                      f"1 thread; max rel QoI deviation GPU vs oracle on them = {dev:.2e}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute calls: no GPU here)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+from oracle import fin_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from bayesianinferencedl_amd import _build, _ffi
+    path = _build.build()
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "finrom.h")).read()
+    declared = set(re.findall(r"\b(finrom_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in finrom.h but not exported"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    lib.finrom_version.restype = ctypes.c_int
+    assert lib.finrom_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from bayesianinferencedl_amd import _ffi
+    monkeypatch.setenv("FINROM_LIB", "/nonexistent/libfinrom_hip.so")
+    monkeypatch.setattr(_ffi, "_lib", None)
+    with pytest.raises(_ffi.FinromError, match="no CPU fallback"):
+        _ffi.lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bayesianinferencedl_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(d, f)
+
+
+@pytest.mark.parametrize("m", [4, 12])
+def test_package_operators_match_oracle(problems, spaces, m):
+    prob = problems(m); ops = spaces(m).operators()
+    assert np.array_equal(prob.coords, ops.mesh.coords)
+    rng = np.random.default_rng(0)
+    k = np.exp(0.3 * rng.standard_normal(prob.n)); th = rng.uniform(0.1, 10, 9)
+    assert abs(prob.assemble_fom_loops(k) - ops.csr(ops.fom_values(k))).max() < 1e-13
+    assert abs(prob.assemble_affine(th) - ops.csr(ops.affine_values(th))).max() < 1e-13
+    assert np.allclose(prob.S, ops.S, atol=1e-16) and np.array_equal(prob.B, ops.F)
+    fo = O.FinOracle(prob)
+    k9 = rng.uniform(0.1, 10, 9); k5 = rng.uniform(0.1, 10, 5)
+    assert np.array_equal(fo.nine_param_to_function(k9), ops.N9 @ k9)
+    assert np.array_equal(fo.five_param_to_function(k5), ops.N9 @ (ops.E59 @ k5))
+    assert sorted(map(tuple, ops.mesh.robin_facets.tolist())) == sorted(prob.robin)
+
+
+@pytest.mark.parametrize("ordering", ["auto", "md", "rcm", "natural"])
+def test_cholesky_plan_schedule_reproduces_the_solve(spaces, ordering):
+    """Execute the device schedule in NumPy (same order of operations as fom_kernels.hip)."""
+    from bayesianinferencedl_amd.symbolic import CholeskyPlan
+    ops = spaces(4).operators()
+    plan = CholeskyPlan(ops.indptr, ops.indices, ops.n, ordering)
+    rng = np.random.default_rng(1)
+    k = np.exp(0.3 * rng.standard_normal(ops.n))
+    c0, ptr, idx, w = plan.entry_table(ops.robin_vals, ops.W_field)
+    L = np.zeros(plan.nnzL); invd = np.zeros(ops.n); y = np.zeros(ops.n)
+    F = ops.F[plan.perm]
+    for i in range(ops.n):
+        for e in range(plan.row_ptr[i], plan.row_ptr[i + 1]):
+            acc = c0[e] + w[ptr[e]:ptr[e + 1]] @ k[idx[ptr[e]:ptr[e + 1]]]
+            q = slice(plan.pair_ptr[e], plan.pair_ptr[e + 1])
+            acc -= L[plan.pair_a[q]] @ L[plan.pair_b[q]]
+            if e == plan.row_ptr[i + 1] - 1:
+                L[e] = np.sqrt(acc); invd[i] = 1 / L[e]
+            else:
+                L[e] = acc * invd[plan.ent_col[e]]
+        off = slice(plan.row_ptr[i], plan.row_ptr[i + 1] - 1)
+        y[i] = (F[i] - L[off] @ y[plan.ent_col[off]]) * invd[i]
+    for i in range(ops.n - 1, -1, -1):
+        c = slice(plan.col_ptr[i], plan.col_ptr[i + 1])
+        y[i] = (y[i] - L[plan.col_ent[c]] @ y[plan.col_row[c]]) * invd[i]
+    wsol = np.empty(ops.n); wsol[plan.perm] = y
+    ref = spl.spsolve(ops.csr(ops.fom_values(k)).tocsc(), ops.F)
+    assert np.linalg.norm(wsol - ref) < 1e-12 * np.linalg.norm(ref)
+    assert plan.npairs == sum(len(a) for a in [plan.pair_a])
+
+
+def test_function_space_shim(spaces):
+    from bayesianinferencedl_amd.fem import Function
+    V = spaces(4)
+    assert V.dim() == len(V.dofmap().dofs()) == V.mesh().num_vertices() == 245
+    assert V.tabulate_dof_coordinates().shape == (245, 2)
+    f = Function(V); g = Function(V)
+    f.vector().set_local(np.arange(245.0)); g.assign(f)
+    g.vector().axpy(2.0, f.vector())
+    assert np.array_equal(g.vector()[:], 3 * np.arange(245.0))
+    v = g.vector()[:]; v[0] = -1
+    assert g.vector()[0] == 0.0                      # slices are copies, as with dolfin vectors
+
+
+def test_get_space_resolution_mapping():
+    from bayesianinferencedl_amd.fom.thermal_fin import get_space
+    assert get_space(40).dim() == 1597               # reference: resolution 40 -> 1446 (mshr)
+    assert get_space(40) is get_space(40)
+
+
+def test_gaussian_field_matches_oracle(problems, spaces):
+    from bayesianinferencedl_amd.bayesian_inference.gaussian_field import make_cov_chol
+    for kern in ("m52", "sq_exp", "m32"):
+        assert np.array_equal(make_cov_chol(spaces(4), kern, 1.6), O.make_cov_chol(problems(4).coords, kern, 1.6))
+
+
+def test_shard_bounds_cover_everything():
+    from bayesianinferencedl_amd.distributed import shard_bounds
+    for total in (0, 1, 7, 100000, 1000003):
+        for world in (1, 2, 4, 8):
+            b = [shard_bounds(total, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == total
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+
+
+def test_gloo_world2_gather_is_identical_to_single_process(tmp_path):
+    """N>1 path on CPU: 2 ranks (gloo) each fill their shard from the GLOBAL sample index, gather,
+    and must reproduce the single-process array bit for bit (SURVEY 8(e) determinism)."""
+    script = tmp_path / "w.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, torch, torch.distributed as dist
+from bayesianinferencedl_amd.distributed import shard_bounds, gather_rows
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+total = 1001
+X = np.random.default_rng(3).uniform(0.1, 10, (total, 5))      # keyed by global sample index
+lo, hi = shard_bounds(total, rank, world)
+local = torch.from_numpy(np.stack([X[lo:hi].sum(1), X[lo:hi].prod(1)], 1))   # stand-in per-sample result
+full = gather_rows(local, world, total)
+ref = np.stack([X.sum(1), X.prod(1)], 1)
+assert np.array_equal(full.numpy(), ref), "gathered result differs from the single-process result"
+if rank == 0: print("OK", full.shape)
+dist.destroy_process_group()
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout
