@@ -175,6 +175,11 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
     for (int q = a->pair_ptr[e]; q < a->pair_ptr[e + 1]; ++q)
       if (a->pair_a[q] < 0 || a->pair_a[q] >= e || a->pair_b[q] < 0 || a->pair_b[q] >= e) return bad("pair_a/pair_b (must precede the entry)");
   }
+  for (int i = 0; i < n; ++i) {           // pair_a must be an entry of the row being eliminated (LDS row cache)
+    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e)
+      for (int q = a->pair_ptr[e]; q < a->pair_ptr[e + 1]; ++q)
+        if (a->pair_a[q] < a->row_ptr[i]) return bad("pair_a (must lie in the row of its entry)");
+  }
   if (a->asm_ptr[0] != 0 || a->asm_ptr[nnzL] != a->nasm) return bad("asm_ptr");
   for (int e = 0; e < nnzL; ++e) if (a->asm_ptr[e + 1] < a->asm_ptr[e]) return bad("asm_ptr");
   for (int t = 0; t < a->nasm; ++t) if (a->asm_idx[t] < 0 || a->asm_idx[t] >= a->xdim) return bad("asm_idx");
@@ -197,11 +202,25 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   auto* h = new finrom_fom_s();
   FomDev& d = h->d;
   d.n = n; d.nnzL = nnzL; d.npairs = a->npairs; d.xdim = a->xdim; d.n_obs = a->n_obs;
+  d.maxrow = 1;
+  d.debug_phases = 7;
+  if (const char* ph = getenv("FINROM_FOM_PHASES")) d.debug_phases = atoi(ph);
+  for (int i = 0; i < n; ++i) d.maxrow = std::max(d.maxrow, a->row_ptr[i + 1] - a->row_ptr[i]);
+  std::vector<int> pair_mid(nnzL);
+  for (int i = 0; i < n; ++i)
+    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e) {
+      int q = a->pair_ptr[e];
+      while (q < a->pair_ptr[e + 1] && a->pair_a[q] - a->row_ptr[i] < FOM_ROW_CACHE) ++q;
+      for (int t = q; t < a->pair_ptr[e + 1]; ++t)
+        if (a->pair_a[t] - a->row_ptr[i] < FOM_ROW_CACHE) { delete h; set_error("fom_create: pair_a must ascend within an entry"); return FINROM_ERR_ARG; }
+      pair_mid[e] = q;
+    }
   int rc = 0;
   const int nobsnz = a->n_obs > 0 ? a->obs_ptr[a->n_obs] : 0;
   if (!rc) rc = up(h->owned, &d.row_ptr, a->row_ptr, n + 1);
   if (!rc) rc = up(h->owned, &d.ent_col, a->ent_col, nnzL);
   if (!rc) rc = up(h->owned, &d.pair_ptr, a->pair_ptr, nnzL + 1);
+  if (!rc) rc = up(h->owned, &d.pair_mid, pair_mid.data(), nnzL);
   if (!rc) rc = up(h->owned, &d.pair_a, a->pair_a, a->npairs);
   if (!rc) rc = up(h->owned, &d.pair_b, a->pair_b, a->npairs);
   if (!rc) rc = up(h->owned, &d.asm_c0, a->asm_c0, nnzL);
@@ -323,12 +342,12 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
   if (!h || S < 0 || (S > 0 && (!theta || (!qoi_r && h->d.n_obs > 0)))) { set_error("rom_solve: bad argument"); return FINROM_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const RomDev& d = h->d;
-  const size_t per_sample = ((size_t)d.rp * d.rp + d.rp) * sizeof(double);
+  const size_t per_sample = ((size_t)d.rp * (d.rp + 1) / 2 + d.rp) * sizeof(double);
   int64_t chunk = std::max<int64_t>(4, (int64_t)(((size_t)16 << 30) / per_sample) / 4 * 4);
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t Sc = std::min(chunk, S - s0);
     int rc;
-    if ((rc = h->Ar.reserve((size_t)Sc * d.rp * d.rp * sizeof(double)))) return rc;
+    if ((rc = h->Ar.reserve((size_t)Sc * (d.rp * (d.rp + 1) / 2) * sizeof(double)))) return rc;
     if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
     if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, st))) return rc;
     if ((rc = launch_rom_solve(d, (const double*)h->Ar.p, (const double*)h->Br.p, Sc, w_r ? w_r + s0 * d.r : nullptr,

@@ -8,7 +8,8 @@
 
 namespace finrom {
 
-constexpr int WAVE = 64;  // gfx950 wavefront; the batch is blocked in groups of 64 samples
+constexpr int WAVE = 64;
+constexpr int FOM_ROW_CACHE = 44;   // LDS slots (512 B each) caching the row being eliminated  // gfx950 wavefront; the batch is blocked in groups of 64 samples
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
@@ -56,8 +57,9 @@ struct Scratch {
 
 // ---- FOM ------------------------------------------------------------------------------
 struct FomDev {
-  int n, nnzL, npairs, xdim, n_obs;
-  const int* row_ptr; const int* ent_col; const int* pair_ptr; const int* pair_a; const int* pair_b;
+  int debug_phases;   // bit 0 factor+forward, 1 backward, 2 QoI (FINROM_FOM_PHASES, timing experiments only; default 7)
+  int n, nnzL, npairs, xdim, n_obs, maxrow;   // maxrow = longest row of L (entries incl. diagonal)
+  const int* row_ptr; const int* ent_col; const int* pair_ptr; const int* pair_mid; const int* pair_a; const int* pair_b;
   const double* asm_c0; const int* asm_ptr; const int* asm_idx; const double* asm_w;
   const double* rhs; const int* col_ptr; const int* col_ent; const int* col_row;
   const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;

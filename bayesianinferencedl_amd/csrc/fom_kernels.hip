@@ -53,15 +53,21 @@ __global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restr
                                                  double* __restrict__ Lw, double* __restrict__ invd,
                                                  double* __restrict__ yw, double* __restrict__ qoi,
                                                  int* __restrict__ info) {
+  // LDS: the entries of the row being eliminated, [maxrow][64] (lane-private column of 8-B slots:
+  // conflict-free ds_read_b64 / ds_write_b64).  The "a" operand of every multiply-add is an entry
+  // of the current row, so only the "b" operand (an earlier row of L) comes from global memory.
+  extern __shared__ __attribute__((aligned(16))) double rowc[];
   const int lane = threadIdx.x;
   const int64_t blk = blockIdx.x;
   const double* xb = xT + blk * (int64_t)p.xdim * 64 + lane;
   double* Lb = Lw + blk * (int64_t)p.nnzL * 64 + lane;
   double* ib = invd + blk * (int64_t)p.n * 64 + lane;
   double* yb = yw + blk * (int64_t)p.n * 64 + lane;
+  double* rc = rowc + lane;
   int bad = 0;
 
   // ---- numeric factorisation A = L L^T, row by row, fused with  L y = F ---------------
+  if (p.debug_phases & 1)
   for (int i = 0; i < p.n; ++i) {
     const int e0 = p.row_ptr[i], e1 = p.row_ptr[i + 1];
     double inv_i = 0.0;
@@ -70,21 +76,28 @@ __global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restr
       double acc = p.asm_c0[e];
       for (int t = p.asm_ptr[e], t1 = p.asm_ptr[e + 1]; t < t1; ++t)
         acc = fma(p.asm_w[t], xb[(int64_t)p.asm_idx[t] * 64], acc);
-      // acc -= sum_k L_ik L_jk
+      // acc -= sum_k L_ik L_jk : L_ik from the LDS row cache, L_jk from global
+      double acc2 = 0.0;
       int q = p.pair_ptr[e];
-      const int q1 = p.pair_ptr[e + 1];
-      for (; q + 4 <= q1; q += 4) {
-        const int a0 = p.pair_a[q], a1 = p.pair_a[q + 1], a2 = p.pair_a[q + 2], a3 = p.pair_a[q + 3];
-        const int b0 = p.pair_b[q], b1 = p.pair_b[q + 1], b2 = p.pair_b[q + 2], b3 = p.pair_b[q + 3];
-        const double la0 = Lb[(int64_t)a0 * 64], lb0 = Lb[(int64_t)b0 * 64];
-        const double la1 = Lb[(int64_t)a1 * 64], lb1 = Lb[(int64_t)b1 * 64];
-        const double la2 = Lb[(int64_t)a2 * 64], lb2 = Lb[(int64_t)b2 * 64];
-        const double la3 = Lb[(int64_t)a3 * 64], lb3 = Lb[(int64_t)b3 * 64];
-        acc = fma(-la0, lb0, acc); acc = fma(-la1, lb1, acc);
-        acc = fma(-la2, lb2, acc); acc = fma(-la3, lb3, acc);
+      const int q1 = p.pair_mid[e];            // pairs whose a-operand sits in the LDS row cache
+      for (; q + 8 <= q1; q += 8) {
+        double lb[8], la[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lb[u] = Lb[(int64_t)p.pair_b[q + u] * 64];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) la[u] = rc[(p.pair_a[q + u] - e0) * 64];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { acc = fma(-la[u], lb[u], acc); acc2 = fma(-la[u + 1], lb[u + 1], acc2); }
       }
-      for (; q < q1; ++q)
-        acc = fma(-Lb[(int64_t)p.pair_a[q] * 64], Lb[(int64_t)p.pair_b[q] * 64], acc);
+      for (; q + 2 <= q1; q += 2) {
+        const double lb0 = Lb[(int64_t)p.pair_b[q] * 64], lb1 = Lb[(int64_t)p.pair_b[q + 1] * 64];
+        acc = fma(-rc[(p.pair_a[q] - e0) * 64], lb0, acc);
+        acc2 = fma(-rc[(p.pair_a[q + 1] - e0) * 64], lb1, acc2);
+      }
+      if (q < q1) { acc = fma(-rc[(p.pair_a[q] - e0) * 64], Lb[(int64_t)p.pair_b[q] * 64], acc); ++q; }
+      for (const int q2 = p.pair_ptr[e + 1]; q < q2; ++q)      // tail of very long rows: both operands from global
+        acc2 = fma(-Lb[(int64_t)p.pair_a[q] * 64], Lb[(int64_t)p.pair_b[q] * 64], acc2);
+      acc += acc2;
       if (e == e1 - 1) {                       // diagonal
         bad |= !(acc > 0.0);
         const double d = sqrt(acc);
@@ -92,16 +105,19 @@ __global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restr
         Lb[(int64_t)e * 64] = d;
         ib[(int64_t)i * 64] = inv_i;
       } else {
-        Lb[(int64_t)e * 64] = acc * ib[(int64_t)p.ent_col[e] * 64];
+        const double l = acc * ib[(int64_t)p.ent_col[e] * 64];
+        Lb[(int64_t)e * 64] = l;
+        if (e - e0 < FOM_ROW_CACHE) rc[(e - e0) * 64] = l;
       }
     }
     double yi = p.rhs[i];
     for (int e = e0; e < e1 - 1; ++e)
-      yi = fma(-Lb[(int64_t)e * 64], yb[(int64_t)p.ent_col[e] * 64], yi);
+      yi = fma(-((e - e0 < FOM_ROW_CACHE) ? rc[(e - e0) * 64] : Lb[(int64_t)e * 64]), yb[(int64_t)p.ent_col[e] * 64], yi);
     yb[(int64_t)i * 64] = yi * inv_i;
   }
 
   // ---- L^T w = y, in place (w overwrites y) -------------------------------------------
+  if (p.debug_phases & 2)
   for (int i = p.n - 1; i >= 0; --i) {
     double wi = yb[(int64_t)i * 64];
     for (int c = p.col_ptr[i], c1 = p.col_ptr[i + 1]; c < c1; ++c)
@@ -112,6 +128,7 @@ __global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restr
   // ---- QoI = B_obs w  (fom :408-412) ---------------------------------------------------
   const int64_t s = blk * 64 + lane;
   const double nanv = __builtin_nan("");
+  if (p.debug_phases & 4)
   for (int o = 0; o < p.n_obs; ++o) {
     double qv = 0.0;
     for (int t = p.obs_ptr[o], t1 = p.obs_ptr[o + 1]; t < t1; ++t)
@@ -127,7 +144,9 @@ int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, doubl
                double* yw, double* qoi, int* info, hipStream_t st) {
   if (nblk == 0) return 0;
   ScopedKernelTimer t(K_FOM, st);
-  hipLaunchKernelGGL(fom_kernel, dim3((unsigned)nblk), dim3(64), 0, st, p, xT, S, Lw, invd, yw, qoi, info);
+  // 44 slots x 512 B = 22 KiB per wave: 7 waves per CU (1792 resident waves >= 1563 for 100k samples)
+  const size_t lds = (size_t)(p.maxrow < FOM_ROW_CACHE ? p.maxrow : FOM_ROW_CACHE) * 64 * sizeof(double);
+  hipLaunchKernelGGL(fom_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, xT, S, Lw, invd, yw, qoi, info);
   FR_HIP(hipGetLastError());
   return 0;
 }

@@ -62,8 +62,11 @@ __global__ __launch_bounds__(256) void rom_proj_kernel(RomDev p, const double* _
       }
   }
 
-  // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15]
-  double* A = Ar + s * (int64_t)p.rp * p.rp;
+  // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15].
+  // A_r is symmetric: tile (ti <= tj) element (row, col) is written as the LOWER element
+  // (i = col, k = row) of the packed column-major lower triangle the solve kernel reads.
+  const int R = p.rp;
+  double* A = Ar + s * (int64_t)(R * (R + 1) / 2);
   int idx = 0;
 #pragma unroll
   for (int ti = 0; ti < NB; ++ti)
@@ -72,8 +75,7 @@ __global__ __launch_bounds__(256) void rom_proj_kernel(RomDev p, const double* _
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row = 16 * ti + q + 4 * g, col = 16 * tj + c;
-        A[row * p.rp + col] = acc[idx][g];
-        if (ti != tj) A[col * p.rp + row] = acc[idx][g];
+        if (ti != tj || col >= row) A[row * R - (row * (row - 1)) / 2 + col - row] = acc[idx][g];
       }
       ++idx;
     }
@@ -103,85 +105,148 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
 }
 
 // ---------------------------------------------------------------------------------------
-// reduced solve: one workgroup per sample, A_r in LDS, right-looking Cholesky (A_r is SPD;
-// the reference calls LAPACK dgesv, :304 -- same solution), two triangular solves, QoI.
+// reduced solve: one WAVE per sample (workgroup = 64 threads), lane = row of A_r.
+// A_r arrives as the packed lower triangle, stored by columns (column k holds rows k..R-1
+// contiguously, so a wave reading column k over its rows is conflict-free in LDS).
+// Left-looking Cholesky in panels of 4 columns: per k the wave does 1 vector + 4 broadcast
+// LDS reads for 4 (8 with the second row set) multiply-adds; pivots travel by lane shuffles.
+// A_r is SPD; the reference calls LAPACK dgesv (rom :304) -- same solution.
+// Rows r..R-1 are padding (zero rows of psi^T psi): they get a unit diagonal.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rom_solve_kernel(RomDev p, const double* __restrict__ Ar,
-                                                        const double* __restrict__ Br, int64_t S,
-                                                        double* __restrict__ w_r, double* __restrict__ qoi_r,
-                                                        double* __restrict__ Ar_out, double* __restrict__ Br_out,
-                                                        int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int r = p.r, rp = p.rp, ld = rp + 1;
-  double* A = sm;                 // [rp][ld]
-  double* b = sm + rp * ld;       // [rp]
-  int& bad_s = *reinterpret_cast<int*>(b + rp);   // keep ALL LDS in the dynamic region (16-B aligned base)
-  const int tid = threadIdx.x;
-  const int64_t s = blockIdx.x;
-  const double* As = Ar + s * (int64_t)rp * rp;
-  if (tid == 0) bad_s = 0;
-  for (int t = tid; t < rp * rp; t += 256) A[(t / rp) * ld + (t % rp)] = As[t];
-  for (int t = tid; t < rp; t += 256) b[t] = Br[s * rp + t];
-  __syncthreads();
-  if (Ar_out != nullptr)
-    for (int t = tid; t < r * r; t += 256) Ar_out[s * (int64_t)r * r + t] = A[(t / r) * ld + (t % r)];
-  if (Br_out != nullptr)
-    for (int t = tid; t < r; t += 256) Br_out[s * r + t] = b[t];
+__device__ __forceinline__ int col_start(int k, int R) { return k * R - (k * (k - 1)) / 2; }
 
-  const int tx = tid & 15, ty = tid >> 4;
-  for (int k = 0; k < r; ++k) {
-    __syncthreads();
-    const double d = A[k * ld + k];
-    if (!(d > 0.0) && tid == 0) bad_s = 1;
-    const double inv = 1.0 / sqrt(d);
-    __syncthreads();
-    for (int i = k + tid; i < r; i += 256) A[i * ld + k] = (i == k) ? sqrt(d) : A[i * ld + k] * inv;
-    __syncthreads();
-    for (int i = k + 1 + ty; i < r; i += 16) {
-      const double lik = A[i * ld + k];
-      for (int j = k + 1 + tx; j <= i; j += 16) A[i * ld + j] = fma(-lik, A[j * ld + k], A[i * ld + j]);
+__global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* __restrict__ Arp,
+                                                       const double* __restrict__ Br, int64_t S,
+                                                       double* __restrict__ w_r, double* __restrict__ qoi_r,
+                                                       double* __restrict__ Ar_out, double* __restrict__ Br_out,
+                                                       int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int r = p.r, R = p.rp, np = R * (R + 1) / 2;
+  double* Lm = sm;            // [np] packed lower triangle, column-major
+  double* invd = sm + np;     // [R]
+  double* xs = invd + R;      // [R]
+  const int lane = threadIdx.x;
+  const int64_t s = blockIdx.x;
+  const double* As = Arp + s * (int64_t)np;
+  {   // np = R(R+1)/2 is even for R a multiple of 16: copy as 16-byte vectors, 8 loads in flight
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* src = reinterpret_cast<const d2*>(As);
+    d2* dst = reinterpret_cast<d2*>(Lm);
+    const int nv = np / 2;
+    int t = lane;
+    for (; t + 7 * 64 < nv; t += 8 * 64) {
+      d2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[t + u * 64];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dst[t + u * 64] = v[u];
     }
+    for (; t < nv; t += 64) dst[t] = src[t];
   }
-  // L y = b
-  for (int k = 0; k < r; ++k) {
+  __syncthreads();
+  for (int i = r + lane; i < R; i += 64) Lm[col_start(i, R)] = 1.0;
+  const int i0 = lane, i1 = lane + 64;
+  const bool v1 = i1 < R;
+  double b0 = (i0 < R) ? Br[s * R + i0] : 0.0;
+  double b1 = v1 ? Br[s * R + i1] : 0.0;
+  if (Ar_out != nullptr)
+    for (int t = lane; t < r * r; t += 64) {
+      const int i = t / r, j = t - i * r;
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      Ar_out[s * (int64_t)r * r + t] = Lm[col_start(lo, R) + hi - lo];
+    }
+  if (Br_out != nullptr) {
+    if (i0 < r) Br_out[s * r + i0] = b0;
+    if (i1 < r) Br_out[s * r + i1] = b1;
+  }
+  __syncthreads();
+
+  int bad = 0;
+  for (int j0 = 0; j0 < R; j0 += 4) {
+    double a0[4], a1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int pc = j0 + c;
+      a0[c] = (i0 >= pc && i0 < R) ? Lm[col_start(pc, R) + i0 - pc] : 0.0;
+      a1[c] = (v1 && i1 >= pc) ? Lm[col_start(pc, R) + i1 - pc] : 0.0;
+    }
+    const bool act0 = i0 >= j0 && i0 < R;
+#pragma unroll 4
+    for (int k = 0; k < j0; ++k) {
+      const int ck = col_start(k, R) - k;
+      const double l0 = act0 ? Lm[ck + i0] : 0.0;
+      const double l1 = (v1 && i1 >= j0) ? Lm[ck + i1] : 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double bc = Lm[ck + j0 + c];
+        a0[c] = fma(-l0, bc, a0[c]);
+        a1[c] = fma(-l1, bc, a1[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int pc = j0 + c;
+      const double piv = (pc < 64) ? __shfl(a0[c], pc) : __shfl(a1[c], pc - 64);
+      bad |= !(piv > 0.0);
+      const double d = sqrt(piv), inv = 1.0 / d;
+      const double l0 = (i0 > pc) ? a0[c] * inv : ((i0 == pc) ? d : 0.0);
+      const double l1 = (i1 > pc) ? a1[c] * inv : ((i1 == pc) ? d : 0.0);
+      const int cp = col_start(pc, R) - pc;
+      if (i0 >= pc && i0 < R) Lm[cp + i0] = l0;
+      if (v1 && i1 >= pc) Lm[cp + i1] = l1;
+      if (lane == 0) invd[pc] = inv;
+#pragma unroll
+      for (int c2 = c + 1; c2 < 4; ++c2) {
+        const int p2 = j0 + c2;
+        const double lp = (p2 < 64) ? __shfl(l0, p2) : __shfl(l1, p2 - 64);
+        a0[c2] = fma(-l0, lp, a0[c2]);
+        a1[c2] = fma(-l1, lp, a1[c2]);
+      }
+    }
     __syncthreads();
-    const double yk = b[k] / A[k * ld + k];
-    __syncthreads();
-    if (tid == 0) b[k] = yk;
-    for (int i = k + 1 + tid; i < r; i += 256) b[i] = fma(-A[i * ld + k], yk, b[i]);
+  }
+  // L y = b   (lane = row; y_k broadcast by shuffle)
+  for (int k = 0; k < R; ++k) {
+    const double bk = (k < 64) ? __shfl(b0, k) : __shfl(b1, k - 64);
+    const double yk = bk * invd[k];
+    const int ck = col_start(k, R) - k;
+    if (i0 == k) b0 = yk; else if (i0 > k && i0 < R) b0 = fma(-Lm[ck + i0], yk, b0);
+    if (i1 == k) b1 = yk; else if (v1 && i1 > k) b1 = fma(-Lm[ck + i1], yk, b1);
   }
   // L^T x = y
-  for (int k = r - 1; k >= 0; --k) {
-    __syncthreads();
-    const double xk = b[k] / A[k * ld + k];
-    __syncthreads();
-    if (tid == 0) b[k] = xk;
-    for (int i = tid; i < k; i += 256) b[i] = fma(-A[k * ld + i], xk, b[i]);
+  for (int k = R - 1; k >= 0; --k) {
+    const double bk = (k < 64) ? __shfl(b0, k) : __shfl(b1, k - 64);
+    const double xk = bk * invd[k];
+    if (i0 == k) b0 = xk; else if (i0 < k) b0 = fma(-Lm[col_start(i0, R) + k - i0], xk, b0);
+    if (i1 == k) b1 = xk; else if (v1 && i1 < k) b1 = fma(-Lm[col_start(i1, R) + k - i1], xk, b1);
   }
-  __syncthreads();
-  const int bad = bad_s;
   const double nanv = __builtin_nan("");
-  if (w_r != nullptr)
-    for (int t = tid; t < r; t += 256) w_r[s * r + t] = bad ? nanv : b[t];
-  for (int o = tid; o < p.n_obs; o += 256) {
+  if (i0 < R) xs[i0] = b0;
+  if (v1) xs[i1] = b1;
+  __syncthreads();
+  if (w_r != nullptr) {
+    if (i0 < r) w_r[s * r + i0] = bad ? nanv : b0;
+    if (i1 < r) w_r[s * r + i1] = bad ? nanv : b1;
+  }
+  for (int o = lane; o < p.n_obs; o += 64) {
     double qv = 0.0;
-    for (int t = 0; t < r; ++t) qv = fma(p.obs_phi[o * r + t], b[t], qv);
+    for (int t = 0; t < r; ++t) qv = fma(p.obs_phi[o * r + t], xs[t], qv);
     qoi_r[s * p.n_obs + o] = bad ? nanv : qv;
   }
-  if (info != nullptr && tid == 0 && bad) info[s] |= 2;
+  if (info != nullptr && lane == 0 && bad) info[s] |= 2;
 }
 
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
                      double* Ar_out, double* Br_out, int* info, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  size_t lds = ((size_t)p.rp * (p.rp + 1) + p.rp + 2) * sizeof(double);
+  size_t lds = ((size_t)p.rp * (p.rp + 1) / 2 + 2 * (size_t)p.rp) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_set = true;
   }
-  hipLaunchKernelGGL(rom_solve_kernel, dim3((unsigned)S), dim3(256), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
+  hipLaunchKernelGGL(rom_solve_kernel, dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
   FR_HIP(hipGetLastError());
   return 0;
 }
