@@ -282,48 +282,80 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   for (int i = 0; i < a->n; ++i) if (a->row_ptr[i + 1] < a->row_ptr[i]) { set_error("rom_create: invalid row_ptr"); return FINROM_ERR_ARG; }
   for (int t = 0; t < a->nterms; ++t) if (a->term_p[t] < 0 || a->term_p[t] > a->P) { set_error("rom_create: invalid term_p"); return FINROM_ERR_ARG; }
   const int r = a->r, NB = (r + 15) / 16, rp = 16 * NB;
-  if (NB > 8) { set_error("rom_create: basis size > 128 not supported yet"); return FINROM_ERR_UNSUPPORTED; }
+  if (NB > 13) { set_error("rom_create: basis size > 208 not supported"); return FINROM_ERR_UNSUPPORTED; }
 
-  // rows sorted by term count so that the 4 rows of a k-step need the same number of slots
-  std::vector<int> order(a->n);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-    return (a->row_ptr[x + 1] - a->row_ptr[x]) > (a->row_ptr[y + 1] - a->row_ptr[y]); });
-  const int nk = (a->n + 3) / 4;
-  std::vector<int> kptr(nk + 1, 0);
-  std::vector<int2> slots;
-  std::vector<double> rhs4((size_t)nk * 4, 0.0);
-  for (int ks = 0; ks < nk; ++ks) {
-    int nt = 0;
-    for (int q = 0; q < 4; ++q) {
-      int idx = ks * 4 + q;
-      if (idx < a->n) { int row = order[idx]; nt = std::max(nt, a->row_ptr[row + 1] - a->row_ptr[row]); rhs4[idx] = a->rhs[row]; }
-    }
-    for (int t = 0; t < nt; ++t)
-      for (int q = 0; q < 4; ++q) {
-        int idx = ks * 4 + q;
-        int2 sl = make_int2(0, 0);          // padded zero r-vector, theta[0] = 1
-        if (idx < a->n) {
-          int row = order[idx];
-          int tt = a->row_ptr[row] + t;
-          if (tt < a->row_ptr[row + 1]) sl = make_int2((tt + 1) * rp, a->term_p[tt]);
-        }
-        slots.push_back(sl);
-      }
-    kptr[ks + 1] = kptr[ks] + nt;
-  }
-  std::vector<double> tv((size_t)(a->nterms + 1) * rp, 0.0);
-  for (int t = 0; t < a->nterms; ++t)
-    std::memcpy(&tv[(size_t)(t + 1) * rp], a->term_val + (size_t)t * r, r * sizeof(double));
-
+  // rows sorted by term count (descending) so that the 4 rows of a k-step need the same number
+  // of slots and the k-steps fall into a few phases of constant term count NT
+  auto cnt = [&](int row) { return a->row_ptr[row + 1] - a->row_ptr[row]; };
+  std::vector<int> order;
+  for (int i = 0; i < a->n; ++i) if (cnt(i) > 0) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cnt(x) > cnt(y); });
+  const int nrows = (int)order.size();
+  const int nk = (nrows + 3) / 4;
   auto* h = new finrom_rom_s();
   RomDev& d = h->d;
-  d.n = a->n; d.r = r; d.rp = rp; d.NB = NB; d.P = a->P; d.n_obs = a->n_obs; d.nk = nk;
+  d.n = a->n; d.r = r; d.rp = rp; d.NB = NB; d.P = a->P; d.n_obs = a->n_obs;
+  d.solve_in_lds = rp <= 176 ? 1 : 0;
+  d.n_phases = 0;
+  std::vector<double> tv; std::vector<int> pidx;
+  auto push_slot = [&](std::vector<double>& T, std::vector<int>& Pi, const std::vector<int>& rows4, int t) {
+    for (int q = 0; q < 4; ++q) {
+      const size_t base = T.size();
+      T.resize(base + rp, 0.0);
+      int pi = 0;
+      if (q < (int)rows4.size() && rows4[q] >= 0) {
+        const int row = rows4[q], tt = a->row_ptr[row] + t;
+        if (tt < a->row_ptr[row + 1]) { std::memcpy(&T[base], a->term_val + (size_t)tt * r, r * sizeof(double)); pi = a->term_p[tt]; }
+      }
+      Pi.push_back(pi);
+    }
+  };
+  int nslots = 0;
+  for (int ks = 0; ks < nk; ++ks) {
+    std::vector<int> rows4;
+    int nt = 0;
+    for (int q = 0; q < 4; ++q) {
+      const int idx = ks * 4 + q;
+      rows4.push_back(idx < nrows ? order[idx] : -1);
+      if (idx < nrows) nt = std::max(nt, cnt(order[idx]));
+    }
+    if (nt > 4) { delete h; set_error("rom_create: a row of psi has more than 4 terms"); return FINROM_ERR_UNSUPPORTED; }
+    if (d.n_phases == 0 || d.phase_nt[d.n_phases - 1] != nt) {
+      if (d.n_phases == ROM_MAX_PHASES) { delete h; set_error("rom_create: too many phases"); return FINROM_ERR_UNSUPPORTED; }
+      d.phase_nt[d.n_phases] = nt; d.phase_ks0[d.n_phases] = ks; d.phase_slot0[d.n_phases] = nslots;
+      ++d.n_phases;
+    }
+    d.phase_ks1[d.n_phases - 1] = ks + 1;
+    for (int t = 0; t < nt; ++t) push_slot(tv, pidx, rows4, t);
+    nslots += nt;
+  }
+  tv.resize(tv.size() + (size_t)4 * 4 * rp, 0.0);          // one k-step of padding for the prefetch
+  pidx.resize(pidx.size() + 16, 0);
+
+  // root rows (F != 0) for B_r = psi^T F
+  std::vector<int> frows;
+  for (int i = 0; i < a->n; ++i) if (a->rhs[i] != 0.0 && cnt(i) > 0) frows.push_back(i);
+  d.rhs_nk = ((int)frows.size() + 3) / 4;
+  d.rhs_nt = 0;
+  for (int row : frows) d.rhs_nt = std::max(d.rhs_nt, cnt(row));
+  std::vector<double> rtv, rf; std::vector<int> rpi;
+  for (int ks = 0; ks < d.rhs_nk; ++ks) {
+    std::vector<int> rows4;
+    for (int q = 0; q < 4; ++q) {
+      const int idx = ks * 4 + q;
+      rows4.push_back(idx < (int)frows.size() ? frows[idx] : -1);
+      rf.push_back(idx < (int)frows.size() ? a->rhs[frows[idx]] : 0.0);
+    }
+    for (int t = 0; t < d.rhs_nt; ++t) push_slot(rtv, rpi, rows4, t);
+  }
+  if (rtv.empty()) { rtv.assign(4 * rp, 0.0); rpi.assign(4, 0); rf.assign(4, 0.0); }
+
   int rc = 0;
-  if (!rc) rc = up(h->owned, &d.kstep_ptr, kptr.data(), kptr.size());
-  if (!rc) rc = up(h->owned, &d.slot, slots.data(), slots.size());
-  if (!rc) rc = up(h->owned, &d.term_val, tv.data(), tv.size());
-  if (!rc) rc = up(h->owned, &d.rhs4, rhs4.data(), rhs4.size());
+  if (!rc) rc = up(h->owned, &d.tv, tv.data(), tv.size());
+  if (!rc) rc = up(h->owned, &d.pidx, pidx.data(), pidx.size());
+  if (!rc) rc = up(h->owned, &d.rhs_tv, rtv.data(), rtv.size());
+  if (!rc) rc = up(h->owned, &d.rhs_pidx, rpi.data(), rpi.size());
+  if (!rc) rc = up(h->owned, &d.rhs_f, rf.data(), rf.size());
   if (!rc) rc = up(h->owned, &d.obs_phi, a->obs_phi, (size_t)a->n_obs * r);
   if (rc) { finrom_rom_destroy(h); return rc; }
   *out = h;

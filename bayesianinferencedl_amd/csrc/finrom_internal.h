@@ -70,12 +70,18 @@ int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, doubl
 int launch_unpack_w(const FomDev& p, const double* yw, int64_t S, double* w, hipStream_t st);
 
 // ---- ROM ------------------------------------------------------------------------------
+constexpr int ROM_MAX_PHASES = 8;
 struct RomDev {
-  int n, r, rp, NB, P, n_obs, nk;      // rp = 16*NB padded basis size, nk = k-steps of 4 rows
-  const int* kstep_ptr;                 // [nk+1] -> slots
-  const int2* slot;                     // [nslots*4] {offset of the r-vector in term_val (in doubles), theta index}
-  const double* term_val;               // padded rows of rp doubles; row 0 is all zeros
-  const double* rhs4;                   // [nk*4] F per psi row (0 for padding rows)
+  int n, r, rp, NB, P, n_obs;           // rp = 16*NB padded basis size
+  int solve_in_lds;                     // packed factor fits in LDS (rp <= 176)
+  // psi tables, rows grouped 4 per k-step and sorted by term count into phases of constant NT
+  int n_phases;
+  int phase_nt[ROM_MAX_PHASES], phase_ks0[ROM_MAX_PHASES], phase_ks1[ROM_MAX_PHASES], phase_slot0[ROM_MAX_PHASES];
+  const double* tv;                     // [(nslots + 4) * 4 * rp]  padded r-vectors, slot-major
+  const int* pidx;                      // [(nslots + 4) * 4]       theta index of each r-vector (0 = constant 1)
+  // rows with a non-zero load F (root nodes), same slot format with a runtime term count
+  int rhs_nk, rhs_nt;
+  const double* rhs_tv; const int* rhs_pidx; const double* rhs_f;
   const double* obs_phi;                // [n_obs x r]
 };
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, hipStream_t st);

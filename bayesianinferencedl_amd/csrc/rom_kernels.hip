@@ -18,48 +18,86 @@ namespace finrom {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int NB>
-__global__ __launch_bounds__(256) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
-                                                       double* __restrict__ Ar, double* __restrict__ Br) {
-  constexpr int NT = NB * (NB + 1) / 2;
-  __shared__ double th[4][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t s = (int64_t)blockIdx.x * 4 + wave;
-  if (s >= S) return;                       // no block-wide barrier below
-  if (lane == 0) th[wave][0] = 1.0;
-  if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
-  __builtin_amdgcn_wave_barrier();
-  const int q = lane >> 4, c = lane & 15;
-
-  d4 acc[NT];
+// One k-step = 4 rows of psi.  Rows are sorted by their number of terms, so the k-steps form a
+// few PHASES with a compile-time term count NT: slot t of k-step ks is 4 padded r-vectors at
+//   tv[((slot0 + (ks - ks0) * NT + t) * 4 + q) * rp + col],   theta index pidx[(slot) * 4 + q],
+// i.e. every address is a function of the loop counter (no dependent index loads), and the raw
+// table values of k-step ks+1 are fetched into registers while the MFMAs of k-step ks issue.
+template <int NB, int NT>
+__device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const int* __restrict__ pidx, int slot, int rp,
+                                           int q, int c, double (&raw)[NT][NB], int (&pi)[NT]) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-  double bacc[NB];
+  for (int t = 0; t < NT; ++t) {
+    const int row = (slot + t) * 4 + q;
+    pi[t] = pidx[row];
+    const double* src = tv + (int64_t)row * rp + c;
 #pragma unroll
-  for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
+    for (int b = 0; b < NB; ++b) raw[t][b] = src[16 * b];
+  }
+}
 
-  for (int ks = 0; ks < p.nk; ++ks) {
+template <int NB, int NW, int W>
+__device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
+  int idx = 0, mine = 0;
+#pragma unroll
+  for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < NB; ++tj) {
+      if (idx % NW == W) {
+        acc[mine] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[mine], 0, 0, 0);
+        ++mine;
+      }
+      ++idx;
+    }
+}
+
+template <int NB, int NW, int W, int NT>
+__device__ __forceinline__ void run_phase(const RomDev& p, int ph, const double* thw, int q, int c,
+                                          d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
+  const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph];
+  if (ks0 >= ks1) return;
+  double raw[NT][NB], nxt[NT][NB];
+  int pi[NT], pn[NT];
+  load_kstep<NB, NT>(p.tv, p.pidx, slot0, p.rp, q, c, raw, pi);
+  for (int ks = ks0; ks < ks1; ++ks) {
+    // prefetch k-step ks+1 (the table is padded by one k-step of zeros, so this never leaves it)
+    load_kstep<NB, NT>(p.tv, p.pidx, slot0 + (ks + 1 - ks0) * NT, p.rp, q, c, nxt, pn);
     double v[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) v[b] = 0.0;
-    for (int t = p.kstep_ptr[ks], t1 = p.kstep_ptr[ks + 1]; t < t1; ++t) {
-      const int2 sl = p.slot[t * 4 + q];
-      const double thp = th[wave][sl.y];
-      const double* src = p.term_val + sl.x + c;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) v[b] = fma(thp, src[16 * b], v[b]);
+    for (int t = 0; t < NT; ++t) {
+      const double thp = thw[pi[t]];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v[b] = fma(thp, raw[t][b], v[b]);
     }
-    const double fk = p.rhs4[ks * 4 + q];
+    mfma_tiles<NB, NW, W>(v, acc);
 #pragma unroll
-    for (int b = 0; b < NB; ++b) bacc[b] = fma(v[b], fk, bacc[b]);
-    int idx = 0;
+    for (int t = 0; t < NT; ++t) {
+      pi[t] = pn[t];
 #pragma unroll
-    for (int ti = 0; ti < NB; ++ti)
+      for (int b = 0; b < NB; ++b) raw[t][b] = nxt[t][b];
+    }
+  }
+}
+
+template <int NB, int NW, int W>
+__device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
+                                              double* __restrict__ Ar, double* __restrict__ Br) {
+  constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
+  const int q = lane >> 4, c = lane & 15;
+  d4 acc[NTL];
 #pragma unroll
-      for (int tj = ti; tj < NB; ++tj) {
-        acc[idx] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[idx], 0, 0, 0);
-        ++idx;
-      }
+  for (int t = 0; t < NTL; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  for (int ph = 0; ph < p.n_phases; ++ph) {
+    switch (p.phase_nt[ph]) {
+      case 1: run_phase<NB, NW, W, 1>(p, ph, thw, q, c, acc); break;
+      case 2: run_phase<NB, NW, W, 2>(p, ph, thw, q, c, acc); break;
+      case 3: run_phase<NB, NW, W, 3>(p, ph, thw, q, c, acc); break;
+      case 4: run_phase<NB, NW, W, 4>(p, ph, thw, q, c, acc); break;
+      default: break;   // rom_create splits rows so that no phase has more than 4 terms
+    }
   }
 
   // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15].
@@ -67,39 +105,97 @@ __global__ __launch_bounds__(256) void rom_proj_kernel(RomDev p, const double* _
   // (i = col, k = row) of the packed column-major lower triangle the solve kernel reads.
   const int R = p.rp;
   double* A = Ar + s * (int64_t)(R * (R + 1) / 2);
-  int idx = 0;
+  int idx = 0, mine = 0;
 #pragma unroll
   for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
     for (int tj = ti; tj < NB; ++tj) {
+      if (idx % NW == W) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = 16 * ti + q + 4 * g, col = 16 * tj + c;
-        if (ti != tj || col >= row) A[row * R - (row * (row - 1)) / 2 + col - row] = acc[idx][g];
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * ti + q + 4 * g, col = 16 * tj + c;
+          if (ti != tj || col >= row) A[row * R - (row * (row - 1)) / 2 + col - row] = acc[mine][g];
+        }
+        ++mine;
       }
       ++idx;
     }
+
+  // B_r = psi^T F (rom :297): F is non-zero on the root nodes only; their rows of psi are rebuilt
+  // here (a handful of k-steps, VALU only) and reduced over the 4 row-groups by lane shuffles.
+  if (W == 0) {
+    double bacc[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    double x = bacc[b];
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    if (q == 0) Br[s * p.rp + 16 * b + c] = x;
+    for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
+    for (int ks = 0; ks < p.rhs_nk; ++ks) {
+      double v[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v[b] = 0.0;
+      for (int t = 0; t < p.rhs_nt; ++t) {
+        const int row = (ks * p.rhs_nt + t) * 4 + q;
+        const double thp = thw[p.rhs_pidx[row]];
+        const double* src = p.rhs_tv + (int64_t)row * p.rp + c;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) v[b] = fma(thp, src[16 * b], v[b]);
+      }
+      const double fk = p.rhs_f[ks * 4 + q];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bacc[b] = fma(v[b], fk, bacc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double x = bacc[b];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      if (q == 0) Br[s * p.rp + 16 * b + c] = x;
+    }
+  }
+}
+
+// NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
+// workgroup is 4 waves = 4/NW samples.
+template <int NB, int NW>
+__global__ __launch_bounds__(256) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+                                                       double* __restrict__ Ar, double* __restrict__ Br) {
+  __shared__ double th[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t s = (int64_t)blockIdx.x * (4 / NW) + wave / NW;
+  if (s >= S) return;                       // no block-wide barrier below
+  if (lane == 0) th[wave][0] = 1.0;
+  if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
+  __builtin_amdgcn_wave_barrier();
+  const double* thw = th[wave];
+  if constexpr (NW == 1) {
+    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br);
+  } else if constexpr (NW == 2) {
+    if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br);
+    else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br);
+  } else {
+    switch (wave % 4) {
+      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br); break;
+      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br); break;
+      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br); break;
+      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br); break;
+    }
   }
 }
 
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_PROJ, st);
-  dim3 grid((unsigned)((S + 3) / 4)), block(256);
+  dim3 block(256);
+#define FR_CASE(N, W)                                                                              \
+  case N: hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + (4 / W) - 1) / (4 / W))), \
+                             block, 0, st, p, theta, S, Ar, Br); break;
   switch (p.NB) {
-#define FR_CASE(N) case N: hipLaunchKernelGGL(rom_proj_kernel<N>, grid, block, 0, st, p, theta, S, Ar, Br); break;
-    FR_CASE(1) FR_CASE(2) FR_CASE(3) FR_CASE(4) FR_CASE(5) FR_CASE(6) FR_CASE(7) FR_CASE(8)
-#undef FR_CASE
+    FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(5, 1) FR_CASE(6, 1)
+    FR_CASE(7, 2) FR_CASE(8, 2) FR_CASE(9, 2)
+    FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 4)
     default:
-      set_error("rom_proj: basis size " + std::to_string(p.r) + " > 128 not supported yet");
+      set_error("rom_proj: basis size " + std::to_string(p.r) + " > 208 not supported");
       return FINROM_ERR_UNSUPPORTED;
   }
+#undef FR_CASE
   FR_HIP(hipGetLastError());
   return 0;
 }
@@ -115,6 +211,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int col_start(int k, int R) { return k * R - (k * (k - 1)) / 2; }
 
+template <bool IN_LDS, int NSET>
 __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* __restrict__ Arp,
                                                        const double* __restrict__ Br, int64_t S,
                                                        double* __restrict__ w_r, double* __restrict__ qoi_r,
@@ -122,13 +219,17 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
                                                        int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int r = p.r, R = p.rp, np = R * (R + 1) / 2;
-  double* Lm = sm;            // [np] packed lower triangle, column-major
-  double* invd = sm + np;     // [R]
-  double* xs = invd + R;      // [R]
+  // The factor lives in LDS when it fits (R <= 176); for larger bases (r = 200) it is factored
+  // in place in the global scratch the projection kernel wrote.  Lane l owns rows l, l+64, ...
+  // (NSET = ceil(R / 64) row sets).
   const int lane = threadIdx.x;
   const int64_t s = blockIdx.x;
-  const double* As = Arp + s * (int64_t)np;
-  {   // np = R(R+1)/2 is even for R a multiple of 16: copy as 16-byte vectors, 8 loads in flight
+  double* As = const_cast<double*>(Arp) + s * (int64_t)np;
+  double* Lm;                                    // [np] packed lower triangle, column-major
+  double* invd;                                  // [R]
+  if constexpr (IN_LDS) { Lm = sm; invd = sm + np; } else { Lm = As; invd = sm; }
+  double* xs = invd + R;                         // [R]
+  if constexpr (IN_LDS) {   // np = R(R+1)/2 is even for R a multiple of 16: copy as 16-byte vectors, 8 loads in flight
     typedef double d2 __attribute__((ext_vector_type(2)));
     const d2* src = reinterpret_cast<const d2*>(As);
     d2* dst = reinterpret_cast<d2*>(Lm);
@@ -145,10 +246,15 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
   }
   __syncthreads();
   for (int i = r + lane; i < R; i += 64) Lm[col_start(i, R)] = 1.0;
-  const int i0 = lane, i1 = lane + 64;
-  const bool v1 = i1 < R;
-  double b0 = (i0 < R) ? Br[s * R + i0] : 0.0;
-  double b1 = v1 ? Br[s * R + i1] : 0.0;
+  int row[NSET];
+  bool ok[NSET];
+  double b[NSET];
+#pragma unroll
+  for (int u = 0; u < NSET; ++u) {
+    row[u] = lane + 64 * u;
+    ok[u] = row[u] < R;
+    b[u] = ok[u] ? Br[s * R + row[u]] : 0.0;
+  }
   if (Ar_out != nullptr)
     for (int t = lane; t < r * r; t += 64) {
       const int i = t / r, j = t - i * r;
@@ -156,77 +262,94 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
       Ar_out[s * (int64_t)r * r + t] = Lm[col_start(lo, R) + hi - lo];
     }
   if (Br_out != nullptr) {
-    if (i0 < r) Br_out[s * r + i0] = b0;
-    if (i1 < r) Br_out[s * r + i1] = b1;
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if (row[u] < r) Br_out[s * r + row[u]] = b[u];
   }
   __syncthreads();
 
+  // value held by the lane that owns row `pr` (pr is wave-uniform)
+  auto bcast = [&](const double (&x)[NSET], int pr) -> double {
+    double out = 0.0;
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if ((pr >> 6) == u) out = __shfl(x[u], pr & 63);
+    return out;
+  };
+
   int bad = 0;
   for (int j0 = 0; j0 < R; j0 += 4) {
-    double a0[4], a1[4];
+    double a[4][NSET];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int pc = j0 + c;
-      a0[c] = (i0 >= pc && i0 < R) ? Lm[col_start(pc, R) + i0 - pc] : 0.0;
-      a1[c] = (v1 && i1 >= pc) ? Lm[col_start(pc, R) + i1 - pc] : 0.0;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) a[c][u] = (ok[u] && row[u] >= pc) ? Lm[col_start(pc, R) + row[u] - pc] : 0.0;
     }
-    const bool act0 = i0 >= j0 && i0 < R;
-#pragma unroll 4
+#pragma unroll 2
     for (int k = 0; k < j0; ++k) {
       const int ck = col_start(k, R) - k;
-      const double l0 = act0 ? Lm[ck + i0] : 0.0;
-      const double l1 = (v1 && i1 >= j0) ? Lm[ck + i1] : 0.0;
+      double l[NSET];
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) l[u] = (ok[u] && row[u] >= j0) ? Lm[ck + row[u]] : 0.0;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const double bc = Lm[ck + j0 + c];
-        a0[c] = fma(-l0, bc, a0[c]);
-        a1[c] = fma(-l1, bc, a1[c]);
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) a[c][u] = fma(-l[u], bc, a[c][u]);
       }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int pc = j0 + c;
-      const double piv = (pc < 64) ? __shfl(a0[c], pc) : __shfl(a1[c], pc - 64);
+      const double piv = bcast(a[c], pc);
       bad |= !(piv > 0.0);
       const double d = sqrt(piv), inv = 1.0 / d;
-      const double l0 = (i0 > pc) ? a0[c] * inv : ((i0 == pc) ? d : 0.0);
-      const double l1 = (i1 > pc) ? a1[c] * inv : ((i1 == pc) ? d : 0.0);
+      double l[NSET];
       const int cp = col_start(pc, R) - pc;
-      if (i0 >= pc && i0 < R) Lm[cp + i0] = l0;
-      if (v1 && i1 >= pc) Lm[cp + i1] = l1;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) {
+        l[u] = (row[u] > pc) ? a[c][u] * inv : ((row[u] == pc) ? d : 0.0);
+        if (ok[u] && row[u] >= pc) Lm[cp + row[u]] = l[u];
+      }
       if (lane == 0) invd[pc] = inv;
 #pragma unroll
       for (int c2 = c + 1; c2 < 4; ++c2) {
-        const int p2 = j0 + c2;
-        const double lp = (p2 < 64) ? __shfl(l0, p2) : __shfl(l1, p2 - 64);
-        a0[c2] = fma(-l0, lp, a0[c2]);
-        a1[c2] = fma(-l1, lp, a1[c2]);
+        const double lp = bcast(l, j0 + c2);
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) a[c2][u] = fma(-l[u], lp, a[c2][u]);
       }
     }
     __syncthreads();
   }
   // L y = b   (lane = row; y_k broadcast by shuffle)
   for (int k = 0; k < R; ++k) {
-    const double bk = (k < 64) ? __shfl(b0, k) : __shfl(b1, k - 64);
-    const double yk = bk * invd[k];
+    const double yk = bcast(b, k) * invd[k];
     const int ck = col_start(k, R) - k;
-    if (i0 == k) b0 = yk; else if (i0 > k && i0 < R) b0 = fma(-Lm[ck + i0], yk, b0);
-    if (i1 == k) b1 = yk; else if (v1 && i1 > k) b1 = fma(-Lm[ck + i1], yk, b1);
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      if (row[u] == k) b[u] = yk;
+      else if (ok[u] && row[u] > k) b[u] = fma(-Lm[ck + row[u]], yk, b[u]);
+    }
   }
   // L^T x = y
   for (int k = R - 1; k >= 0; --k) {
-    const double bk = (k < 64) ? __shfl(b0, k) : __shfl(b1, k - 64);
-    const double xk = bk * invd[k];
-    if (i0 == k) b0 = xk; else if (i0 < k) b0 = fma(-Lm[col_start(i0, R) + k - i0], xk, b0);
-    if (i1 == k) b1 = xk; else if (v1 && i1 < k) b1 = fma(-Lm[col_start(i1, R) + k - i1], xk, b1);
+    const double xk = bcast(b, k) * invd[k];
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      if (row[u] == k) b[u] = xk;
+      else if (row[u] < k) b[u] = fma(-Lm[col_start(row[u], R) + k - row[u]], xk, b[u]);
+    }
   }
   const double nanv = __builtin_nan("");
-  if (i0 < R) xs[i0] = b0;
-  if (v1) xs[i1] = b1;
+#pragma unroll
+  for (int u = 0; u < NSET; ++u)
+    if (ok[u]) xs[row[u]] = b[u];
   __syncthreads();
   if (w_r != nullptr) {
-    if (i0 < r) w_r[s * r + i0] = bad ? nanv : b0;
-    if (i1 < r) w_r[s * r + i1] = bad ? nanv : b1;
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if (row[u] < r) w_r[s * r + row[u]] = bad ? nanv : b[u];
   }
   for (int o = lane; o < p.n_obs; o += 64) {
     double qv = 0.0;
@@ -236,19 +359,33 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
   if (info != nullptr && lane == 0 && bad) info[s] |= 2;
 }
 
+template <bool IN_LDS, int NSET>
+static int launch_solve_t(const RomDev& p, size_t lds, const double* Ar, const double* Br, int64_t S, double* w_r,
+                          double* qoi_r, double* Ar_out, double* Br_out, int* info, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rom_solve_kernel<IN_LDS, NSET>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
                      double* Ar_out, double* Br_out, int* info, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  size_t lds = ((size_t)p.rp * (p.rp + 1) / 2 + 2 * (size_t)p.rp) * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_set = true;
+  const size_t lds = ((p.solve_in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 2 * (size_t)p.rp) * sizeof(double);
+  const int nset = (p.rp + 63) / 64;
+#define FR_SOLVE(L, N) return launch_solve_t<L, N>(p, lds, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info, st)
+  if (p.solve_in_lds) {
+    if (nset == 1) FR_SOLVE(true, 1);
+    if (nset == 2) FR_SOLVE(true, 2);
+    FR_SOLVE(true, 3);
   }
-  hipLaunchKernelGGL(rom_solve_kernel, dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
-  FR_HIP(hipGetLastError());
-  return 0;
+  FR_SOLVE(false, 4);
+#undef FR_SOLVE
 }
 
 }  // namespace finrom
