@@ -81,7 +81,9 @@ struct finrom_fom_s {
 struct finrom_rom_s {
   RomDev d{};
   std::vector<void*> owned;
-  Scratch Ar, Br;
+  Scratch Ar, Br, theta;
+  hipStream_t side = nullptr;          // library-owned stream for the ROM half of finrom_solve_pairs
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 struct finrom_sampler_s { double* U = nullptr; int n = 0; };
 
@@ -365,7 +367,10 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
 void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->Ar.release(); h->Br.release();
+  h->Ar.release(); h->Br.release(); h->theta.release();
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
 }
 
@@ -393,6 +398,41 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
 int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n, const double* k, int64_t S, double* theta, void* stream) {
   if (!Sop || P <= 0 || n <= 0 || S < 0 || (S > 0 && (!k || !theta))) { set_error("subfin_avg: bad argument"); return FINROM_ERR_ARG; }
   return launch_subfin_avg(Sop, P, n, k, S, theta, (hipStream_t)stream);
+}
+
+int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, const double* x, int64_t S,
+                       double* qoi, double* qoi_r, double* err, double* w, double* w_r, double* theta,
+                       int32_t* info, void* stream) {
+  if (!fom || !rom || !Sop || S < 0 || (S > 0 && (!x || !qoi || !qoi_r))) { set_error("solve_pairs: bad argument"); return FINROM_ERR_ARG; }
+  if (fom->d.n_obs != rom->d.n_obs) { set_error("solve_pairs: FOM and ROM observation operators differ in size"); return FINROM_ERR_ARG; }
+  if (S == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (!rom->side) {
+    FR_HIP(hipStreamCreateWithFlags(&rom->side, hipStreamNonBlocking));
+    FR_HIP(hipEventCreateWithFlags(&rom->ev_fork, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&rom->ev_join, hipEventDisableTiming));
+  }
+  int rc;
+  if (!theta) {
+    if ((rc = rom->theta.reserve((size_t)S * rom->d.P * sizeof(double)))) return rc;
+    theta = (double*)rom->theta.p;
+  }
+  static const bool overlap = getenv("FINROM_NO_OVERLAP") == nullptr;   // serial mode: per-kernel profiling
+  hipStream_t side = overlap ? rom->side : st;
+  // fork: everything already queued on the caller's stream (inputs, zeroed info) precedes both halves
+  if (overlap) {
+    FR_HIP(hipEventRecord(rom->ev_fork, st));
+    FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
+  }
+  if ((rc = finrom_fom_solve(fom, x, S, qoi, w, info, st))) return rc;
+  if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, side))) return rc;
+  if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return rc;
+  if (overlap) {
+    FR_HIP(hipEventRecord(rom->ev_join, side));
+    FR_HIP(hipStreamWaitEvent(st, rom->ev_join, 0));
+  }
+  if (err && (rc = launch_sub(qoi, qoi_r, S * (int64_t)fom->d.n_obs, err, st))) return rc;
+  return 0;
 }
 
 int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out) {

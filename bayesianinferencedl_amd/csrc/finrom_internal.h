@@ -9,7 +9,7 @@
 namespace finrom {
 
 constexpr int WAVE = 64;
-constexpr int FOM_ROW_CACHE = 44;   // LDS slots (512 B each) caching the row being eliminated  // gfx950 wavefront; the batch is blocked in groups of 64 samples
+constexpr int FOM_ROW_CACHE = 36;   // LDS slots (512 B each) caching the row being eliminated: 18 KiB per wave, 7 waves per CU leave LDS for the ROM kernels
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what);

@@ -66,63 +66,103 @@ __global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restr
   double* rc = rowc + lane;
   int bad = 0;
 
+  // Every dependent global round trip costs ~1 us here (the wave has nothing else to do), so each
+  // entry issues ALL the loads it needs in one batch: up to 8 b-operands (predicated past the end of
+  // the list), the 1/L_jj it will be scaled by, and the first x values of its assembly.
   // ---- numeric factorisation A = L L^T, row by row, fused with  L y = F ---------------
   if (p.debug_phases & 1)
   for (int i = 0; i < p.n; ++i) {
     const int e0 = p.row_ptr[i], e1 = p.row_ptr[i + 1];
     double inv_i = 0.0;
     for (int e = e0; e < e1; ++e) {
+      int q = p.pair_ptr[e];
+      const int q1 = p.pair_mid[e], q2 = p.pair_ptr[e + 1];
+      const int t0 = p.asm_ptr[e], t1 = p.asm_ptr[e + 1];
+      const bool diag = (e == e1 - 1);
+      // one batch of loads
+      double lb[8], xv[4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) lb[u] = Lb[(int64_t)p.pair_b[(q + u < q1) ? q + u : (q1 > q ? q1 - 1 : 0)] * 64];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = xb[(int64_t)p.asm_idx[(t0 + u < t1) ? t0 + u : 0] * 64];
+      const double invj = diag ? 0.0 : ib[(int64_t)p.ent_col[e] * 64];
       // affine assembly of A_e(x)            (fom :160-161 / rom :154-163)
       double acc = p.asm_c0[e];
-      for (int t = p.asm_ptr[e], t1 = p.asm_ptr[e + 1]; t < t1; ++t)
-        acc = fma(p.asm_w[t], xb[(int64_t)p.asm_idx[t] * 64], acc);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = fma((t0 + u < t1) ? p.asm_w[t0 + u] : 0.0, xv[u], acc);
+      for (int t = t0 + 4; t < t1; ++t) acc = fma(p.asm_w[t], xb[(int64_t)p.asm_idx[t] * 64], acc);
       // acc -= sum_k L_ik L_jk : L_ik from the LDS row cache, L_jk from global
       double acc2 = 0.0;
-      int q = p.pair_ptr[e];
-      const int q1 = p.pair_mid[e];            // pairs whose a-operand sits in the LDS row cache
-      for (; q + 8 <= q1; q += 8) {
-        double lb[8], la[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) lb[u] = Lb[(int64_t)p.pair_b[q + u] * 64];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) la[u] = rc[(p.pair_a[q + u] - e0) * 64];
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) { acc = fma(-la[u], lb[u], acc); acc2 = fma(-la[u + 1], lb[u + 1], acc2); }
+      for (int u = 0; u < 8; u += 2) {
+        const double la0 = (q + u < q1) ? rc[(p.pair_a[q + u] - e0) * 64] : 0.0;
+        const double la1 = (q + u + 1 < q1) ? rc[(p.pair_a[q + u + 1] - e0) * 64] : 0.0;
+        acc = fma(-la0, lb[u], acc); acc2 = fma(-la1, lb[u + 1], acc2);
       }
-      for (; q + 2 <= q1; q += 2) {
-        const double lb0 = Lb[(int64_t)p.pair_b[q] * 64], lb1 = Lb[(int64_t)p.pair_b[q + 1] * 64];
-        acc = fma(-rc[(p.pair_a[q] - e0) * 64], lb0, acc);
-        acc2 = fma(-rc[(p.pair_a[q + 1] - e0) * 64], lb1, acc2);
+      q += 8;
+      for (; q < q1; q += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lb[u] = Lb[(int64_t)p.pair_b[(q + u < q1) ? q + u : q1 - 1] * 64];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+          const double la0 = (q + u < q1) ? rc[(p.pair_a[q + u] - e0) * 64] : 0.0;
+          const double la1 = (q + u + 1 < q1) ? rc[(p.pair_a[q + u + 1] - e0) * 64] : 0.0;
+          acc = fma(-la0, lb[u], acc); acc2 = fma(-la1, lb[u + 1], acc2);
+        }
       }
-      if (q < q1) { acc = fma(-rc[(p.pair_a[q] - e0) * 64], Lb[(int64_t)p.pair_b[q] * 64], acc); ++q; }
-      for (const int q2 = p.pair_ptr[e + 1]; q < q2; ++q)      // tail of very long rows: both operands from global
+      for (q = q1; q < q2; ++q)      // tail of very long rows: both operands from global
         acc2 = fma(-Lb[(int64_t)p.pair_a[q] * 64], Lb[(int64_t)p.pair_b[q] * 64], acc2);
       acc += acc2;
-      if (e == e1 - 1) {                       // diagonal
+      if (diag) {
         bad |= !(acc > 0.0);
         const double d = sqrt(acc);
         inv_i = 1.0 / d;
         Lb[(int64_t)e * 64] = d;
         ib[(int64_t)i * 64] = inv_i;
       } else {
-        const double l = acc * ib[(int64_t)p.ent_col[e] * 64];
+        const double l = acc * invj;
         Lb[(int64_t)e * 64] = l;
         if (e - e0 < FOM_ROW_CACHE) rc[(e - e0) * 64] = l;
       }
     }
-    double yi = p.rhs[i];
-    for (int e = e0; e < e1 - 1; ++e)
-      yi = fma(-((e - e0 < FOM_ROW_CACHE) ? rc[(e - e0) * 64] : Lb[(int64_t)e * 64]), yb[(int64_t)p.ent_col[e] * 64], yi);
-    yb[(int64_t)i * 64] = yi * inv_i;
+    // forward substitution row: y_i = (F_i - sum_k L_ik y_k) / L_ii, loads batched by 8
+    double yi = p.rhs[i], yi2 = 0.0;
+    for (int e = e0; e < e1 - 1; e += 8) {
+      double yv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) yv[u] = yb[(int64_t)p.ent_col[(e + u < e1 - 1) ? e + u : e1 - 2] * 64];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        const int ea = e + u, eb = e + u + 1;
+        const double la = (ea < e1 - 1) ? ((ea - e0 < FOM_ROW_CACHE) ? rc[(ea - e0) * 64] : Lb[(int64_t)ea * 64]) : 0.0;
+        const double lc = (eb < e1 - 1) ? ((eb - e0 < FOM_ROW_CACHE) ? rc[(eb - e0) * 64] : Lb[(int64_t)eb * 64]) : 0.0;
+        yi = fma(-la, yv[u], yi); yi2 = fma(-lc, yv[u + 1], yi2);
+      }
+    }
+    yb[(int64_t)i * 64] = (yi + yi2) * inv_i;
   }
 
-  // ---- L^T w = y, in place (w overwrites y) -------------------------------------------
+  // ---- L^T w = y, in place (w overwrites y); loads batched by 8 -------------------------
   if (p.debug_phases & 2)
   for (int i = p.n - 1; i >= 0; --i) {
-    double wi = yb[(int64_t)i * 64];
-    for (int c = p.col_ptr[i], c1 = p.col_ptr[i + 1]; c < c1; ++c)
-      wi = fma(-Lb[(int64_t)p.col_ent[c] * 64], yb[(int64_t)p.col_row[c] * 64], wi);
-    yb[(int64_t)i * 64] = wi * ib[(int64_t)i * 64];
+    const int c0 = p.col_ptr[i], c1 = p.col_ptr[i + 1];
+    double wi = yb[(int64_t)i * 64], wi2 = 0.0;
+    const double invi = ib[(int64_t)i * 64];
+    for (int c = c0; c < c1; c += 8) {
+      double lv[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int cc = (c + u < c1) ? c + u : c1 - 1;
+        lv[u] = Lb[(int64_t)p.col_ent[cc] * 64];
+        wv[u] = yb[(int64_t)p.col_row[cc] * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        wi = fma((c + u < c1) ? -lv[u] : 0.0, wv[u], wi);
+        wi2 = fma((c + u + 1 < c1) ? -lv[u + 1] : 0.0, wv[u + 1], wi2);
+      }
+    }
+    yb[(int64_t)i * 64] = (wi + wi2) * invi;
   }
 
   // ---- QoI = B_obs w  (fom :408-412) ---------------------------------------------------
@@ -137,14 +177,14 @@ __global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restr
   }
   if (bad)
     for (int i = 0; i < p.n; ++i) yb[(int64_t)i * 64] = nanv;
-  if (info != nullptr && s < S) info[s] |= bad ? 1 : 0;
+  if (info != nullptr && s < S && bad) atomicOr(&info[s], 1);   // the ROM half may set bit 1 concurrently
 }
 
 int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Lw, double* invd,
                double* yw, double* qoi, int* info, hipStream_t st) {
   if (nblk == 0) return 0;
   ScopedKernelTimer t(K_FOM, st);
-  // 44 slots x 512 B = 22 KiB per wave: 7 waves per CU (1792 resident waves >= 1563 for 100k samples)
+  // 36 slots x 512 B = 18 KiB per wave: 7 waves per CU (1792 resident waves >= 1563 for 100k samples)
   const size_t lds = (size_t)(p.maxrow < FOM_ROW_CACHE ? p.maxrow : FOM_ROW_CACHE) * 64 * sizeof(double);
   hipLaunchKernelGGL(fom_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, xT, S, Lw, invd, yw, qoi, info);
   FR_HIP(hipGetLastError());

@@ -36,15 +36,25 @@ __device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const 
   }
 }
 
+// The accumulators MUST live in architectural VGPRs: measured on gfx950 (tools/mfma_f64_variants.hip),
+// v_mfma_f64_16x16x4_f64 issues every 64 cycles (77 TFLOP/s chip-wide) with VGPR accumulators but only
+// every ~131 cycles (38 TFLOP/s) with AGPR accumulators, which is what hipcc picks for the builtin in a
+// kernel of this size.  Hence inline asm with "+v" constraints; hipcc pads nothing around inline asm, so
+// the VALU->MFMA operand hazard is covered by the s_nop in front of each k-step's MFMA group.
 template <int NB, int NW, int W>
 __device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
+  // Bases wider than 128 spill accumulators; spill code next to inline asm is not hazard-safe
+  // (the compiler cannot see that the asm is an MFMA), so those sizes use the compiler-managed builtin.
+  constexpr bool kAsm = NB <= 8;
+  if constexpr (kAsm) asm volatile("s_nop 7" ::: "memory");
   int idx = 0, mine = 0;
 #pragma unroll
   for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
     for (int tj = ti; tj < NB; ++tj) {
       if (idx % NW == W) {
-        acc[mine] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[mine], 0, 0, 0);
+        if constexpr (kAsm) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[mine]) : "v"(v[ti]), "v"(v[tj]));
+        else acc[mine] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[mine], 0, 0, 0);
         ++mine;
       }
       ++idx;
@@ -56,12 +66,11 @@ __device__ __forceinline__ void run_phase(const RomDev& p, int ph, const double*
                                           d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
   const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph];
   if (ks0 >= ks1) return;
-  double raw[NT][NB], nxt[NT][NB];
-  int pi[NT], pn[NT];
+  double raw[NT][NB];
+  int pi[NT];
   load_kstep<NB, NT>(p.tv, p.pidx, slot0, p.rp, q, c, raw, pi);
+#pragma unroll 1
   for (int ks = ks0; ks < ks1; ++ks) {
-    // prefetch k-step ks+1 (the table is padded by one k-step of zeros, so this never leaves it)
-    load_kstep<NB, NT>(p.tv, p.pidx, slot0 + (ks + 1 - ks0) * NT, p.rp, q, c, nxt, pn);
     double v[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) v[b] = 0.0;
@@ -71,13 +80,10 @@ __device__ __forceinline__ void run_phase(const RomDev& p, int ph, const double*
 #pragma unroll
       for (int b = 0; b < NB; ++b) v[b] = fma(thp, raw[t][b], v[b]);
     }
+    // raw is dead now: fetch k-step ks+1 into it; the loads fly while this k-step's MFMAs issue
+    // (the table is padded by one k-step of zeros, so the last prefetch stays inside it)
+    load_kstep<NB, NT>(p.tv, p.pidx, slot0 + (ks + 1 - ks0) * NT, p.rp, q, c, raw, pi);
     mfma_tiles<NB, NW, W>(v, acc);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      pi[t] = pn[t];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) raw[t][b] = nxt[t][b];
-    }
   }
 }
 
@@ -100,6 +106,8 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     }
   }
 
+  // let the last MFMAs retire before their results are read (no hazard padding around inline asm)
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15].
   // A_r is symmetric: tile (ti <= tj) element (row, col) is written as the LOWER element
   // (i = col, k = row) of the packed column-major lower triangle the solve kernel reads.
@@ -155,12 +163,13 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
 // workgroup is 4 waves = 4/NW samples.
 template <int NB, int NW>
-__global__ __launch_bounds__(256) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+__global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br) {
   __shared__ double th[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t s = (int64_t)blockIdx.x * (4 / NW) + wave / NW;
   if (s >= S) return;                       // no block-wide barrier below
+  __builtin_amdgcn_s_setprio(3);            // MFMA-paced waves win issue arbitration over co-resident FOM waves
   if (lane == 0) th[wave][0] = 1.0;
   if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
   __builtin_amdgcn_wave_barrier();
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
     for (int t = 0; t < r; ++t) qv = fma(p.obs_phi[o * r + t], xs[t], qv);
     qoi_r[s * p.n_obs + o] = bad ? nanv : qv;
   }
-  if (info != nullptr && lane == 0 && bad) info[s] |= 2;
+  if (info != nullptr && lane == 0 && bad) atomicOr(&info[s], 2);
 }
 
 template <bool IN_LDS, int NSET>

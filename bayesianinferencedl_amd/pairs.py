@@ -1,11 +1,13 @@
 """Fused FOM + ROM pair evaluation for a batch of conductivity samples: the body of the
-reference's dataset loop (deep_learning/generate_fin_dataset.py:83-100) as four C-ABI calls
-(finrom_fom_solve, finrom_subfin_avg, finrom_rom_solve, finrom_sub), all on the device."""
+reference's dataset loop (deep_learning/generate_fin_dataset.py:83-100) as ONE C-ABI call
+(finrom_solve_pairs): the sparse FOM solve runs on the caller's stream while the sub-fin
+averaging and the LSPG reduced solve run concurrently on a library-owned stream."""
 from __future__ import annotations
 
 import numpy as np
 
-from .engine import SubfinAverager, device_sub
+from ._ffi import check, lib
+from .engine import SubfinAverager, _Batch
 from .fom.forward_solve import Fin
 from .rom.averaged_affine_ROM import AffineROMFin
 
@@ -27,9 +29,15 @@ class FinPairSolver:
         self.n_obs = self.solver.n_obs
 
     def solve_pairs(self, X, want_w=False):
-        fom = self.solver.forward_batch(X, want_w=want_w, params=None if self.params == "field" else self.params)
-        theta = self._avg(X)
-        rom = self.solver_r.forward_nine_param_reduced_batch(theta)
-        err = device_sub(fom["qoi"], rom["qoi_r"])
-        return {"qoi": fom["qoi"], "qoi_r": rom["qoi_r"], "err": err, "w": fom["w"], "w_r": rom["w_r"],
-                "theta": theta, "info": fom["info"] | rom["info"]}
+        fom = self.solver._engine("field" if self.params == "field" else self.params)
+        rom = self.solver_r._rom
+        b = _Batch(X, self.xdim)
+        S = b.S
+        qoi, qp = b.new((S, self.n_obs)); qoi_r, qrp = b.new((S, self.n_obs)); err, ep = b.new((S, self.n_obs))
+        w_r, wrp = b.new((S, rom.r)); theta, tp = b.new((S, rom.P)); info, ip = b.new((S,), "i4")
+        w, wp = (b.new((S, fom.n)) if want_w else (None, None))
+        check(lib().finrom_solve_pairs(fom._h, rom._h, self._avg._S.ptr, b.ptr, S, qp, qrp, ep, wp, wrp, tp, ip, b.stream),
+              "finrom_solve_pairs")
+        return {"qoi": b.out(qoi, (S, self.n_obs)), "qoi_r": b.out(qoi_r, (S, self.n_obs)),
+                "err": b.out(err, (S, self.n_obs)), "w": b.out(w, (S, fom.n)) if want_w else None,
+                "w_r": b.out(w_r, (S, rom.r)), "theta": b.out(theta, (S, rom.P)), "info": b.out(info, (S,), "i4")}

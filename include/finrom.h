@@ -20,7 +20,7 @@
  *    asynchronous on that stream unless stated; a handle is used by one host thread at
  *    a time (the reference classes are not re-entrant either).
  *  - info[s] != 0 marks a failed sample (bit 0: FOM pivot <= 0 or NaN, bit 1: ROM pivot);
- *    its outputs are NaN.
+ *    its outputs are NaN.  info must be zero-initialised by the caller (bits are OR-ed in).
  */
 #ifndef FINROM_H
 #define FINROM_H
@@ -156,6 +156,20 @@ int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n,
 int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out);
 void finrom_sampler_destroy(finrom_sampler_t h);
 int finrom_sampler_draw(finrom_sampler_t h, const double* xi, int64_t S, double* k, void* stream);
+
+/* ---- the dataset-loop body for S samples in one call ---------------------------------- *
+ * (deep_learning/generate_fin_dataset.py:93-100):  FOM solve + QoI on the caller's stream;
+ * concurrently, on a stream owned by the library, theta = Sop x (sub-fin averages of the
+ * field, or of the interpolated per-fin conductivities) and the LSPG reduced solve + QoI;
+ * then err = qoi - qoi_r.  The two halves are independent and are joined with HIP events,
+ * so the latency-bound sparse solve overlaps the MFMA-bound projection.
+ * Sop: device [P x xdim] (P = the ROM's parameter count, xdim = the FOM's).  Optional
+ * outputs (NULL to skip): w [S x n], w_r [S x r], theta [S x P], err [S x n_obs].
+ * info [S] must be zero-initialised by the caller (bits are OR-ed in). */
+int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop,
+                       const double* x, int64_t S,
+                       double* qoi, double* qoi_r, double* err,
+                       double* w, double* w_r, double* theta, int32_t* info, void* stream);
 
 /* ---- elementwise helper: err = qoi - qoi_r (generate_fin_dataset.py:99) -------------- */
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream);
