@@ -19,13 +19,14 @@ class FinromError(RuntimeError):
 
 
 class FomDesc(C.Structure):
-    _fields_ = [("n", C.c_int32), ("nnzL", C.c_int32), ("npairs", C.c_int32), ("xdim", C.c_int32),
-                ("n_obs", C.c_int32), ("nasm", C.c_int32),
-                ("row_ptr", c_i32p), ("ent_col", c_i32p), ("pair_ptr", c_i32p), ("pair_a", c_i32p),
-                ("pair_b", c_i32p), ("asm_c0", c_f64p), ("asm_ptr", c_i32p), ("asm_idx", c_i32p),
-                ("asm_w", c_f64p), ("rhs", c_f64p), ("col_ptr", c_i32p), ("col_ent", c_i32p),
-                ("col_row", c_i32p), ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p),
-                ("perm", c_i32p)]
+    _fields_ = [("n", C.c_int32), ("nnzL", C.c_int32), ("xdim", C.c_int32), ("n_obs", C.c_int32),
+                ("nasm", C.c_int32), ("n_alist", C.c_int32), ("cache_slots", C.c_int32),
+                ("nops_fwd", C.c_int32), ("nops_bwd", C.c_int32),
+                ("a_list", c_i32p), ("asm_c0", c_f64p), ("asm_ptr", c_i32p), ("asm_idx", c_i32p),
+                ("asm_w", c_f64p), ("rhs", c_f64p),
+                ("fwd_kind", c_i32p), ("fwd_a", c_i32p), ("fwd_b", c_i32p), ("fwd_d", c_i32p),
+                ("bwd_kind", c_i32p), ("bwd_a", c_i32p), ("bwd_b", c_i32p), ("bwd_d", c_i32p),
+                ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p), ("perm", c_i32p)]
 
 
 class RomDesc(C.Structure):

@@ -76,7 +76,7 @@ using namespace finrom;
 struct finrom_fom_s {
   FomDev d{};
   std::vector<void*> owned;
-  Scratch xT, Lw, invd, yw;
+  Scratch xT, Gw;
 };
 struct finrom_rom_s {
   RomDev d{};
@@ -156,40 +156,48 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
 int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   if (!a || !out) { set_error("fom_create: null argument"); return FINROM_ERR_ARG; }
   *out = nullptr;
-  if (a->n <= 0 || a->nnzL < a->n || a->xdim <= 0 || a->n_obs < 0 || a->npairs < 0 || a->nasm < 0) {
+  const int n = a->n, nnzL = a->nnzL;
+  if (n <= 0 || nnzL < n || a->xdim <= 0 || a->n_obs < 0 || a->nasm < 0 || a->n_alist < 0 || a->cache_slots < 1 ||
+      a->cache_slots > 64 || a->nops_fwd < 2 * VM_CHUNK || a->nops_bwd < 2 * VM_CHUNK ||
+      a->nops_fwd % (2 * VM_CHUNK) || a->nops_bwd % (2 * VM_CHUNK)) {
     set_error("fom_create: inconsistent sizes"); return FINROM_ERR_ARG;
   }
-  // validate every index the kernel will dereference (a bad index would fault the GPU)
-  const int n = a->n, nnzL = a->nnzL;
+  // validate every index the kernels will dereference (a bad index would fault the GPU) and
+  // the prefetch rule of the op streams
   auto bad = [&](const char* what) { set_error(std::string("fom_create: invalid ") + what); return FINROM_ERR_ARG; };
-  if (a->row_ptr[0] != 0 || a->row_ptr[n] != nnzL) return bad("row_ptr");
-  for (int i = 0; i < n; ++i) {
-    if (a->row_ptr[i + 1] <= a->row_ptr[i]) return bad("row_ptr (empty row)");
-    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e) {
-      const int c = a->ent_col[e];
-      const bool last = e == a->row_ptr[i + 1] - 1;
-      if (last ? c != i : (c < 0 || c >= i)) return bad("ent_col (row must end with its diagonal)");
-    }
-  }
-  if (a->pair_ptr[0] != 0 || a->pair_ptr[nnzL] != a->npairs) return bad("pair_ptr");
-  for (int e = 0; e < nnzL; ++e) {
-    if (a->pair_ptr[e + 1] < a->pair_ptr[e]) return bad("pair_ptr");
-    for (int q = a->pair_ptr[e]; q < a->pair_ptr[e + 1]; ++q)
-      if (a->pair_a[q] < 0 || a->pair_a[q] >= e || a->pair_b[q] < 0 || a->pair_b[q] >= e) return bad("pair_a/pair_b (must precede the entry)");
-  }
-  for (int i = 0; i < n; ++i) {           // pair_a must be an entry of the row being eliminated (LDS row cache)
-    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e)
-      for (int q = a->pair_ptr[e]; q < a->pair_ptr[e + 1]; ++q)
-        if (a->pair_a[q] < a->row_ptr[i]) return bad("pair_a (must lie in the row of its entry)");
-  }
+  const int gsize = nnzL + 2 * n;
+  for (int t = 0; t < a->n_alist; ++t) if (a->a_list[t] < 0 || a->a_list[t] >= nnzL) return bad("a_list");
   if (a->asm_ptr[0] != 0 || a->asm_ptr[nnzL] != a->nasm) return bad("asm_ptr");
   for (int e = 0; e < nnzL; ++e) if (a->asm_ptr[e + 1] < a->asm_ptr[e]) return bad("asm_ptr");
   for (int t = 0; t < a->nasm; ++t) if (a->asm_idx[t] < 0 || a->asm_idx[t] >= a->xdim) return bad("asm_idx");
-  if (a->col_ptr[0] != 0 || a->col_ptr[n] != nnzL - n) return bad("col_ptr");
-  for (int i = 0; i < n; ++i) {
-    if (a->col_ptr[i + 1] < a->col_ptr[i]) return bad("col_ptr");
-    for (int c = a->col_ptr[i]; c < a->col_ptr[i + 1]; ++c)
-      if (a->col_ent[c] < 0 || a->col_ent[c] >= nnzL || a->col_row[c] <= i || a->col_row[c] >= n) return bad("col_ent/col_row");
+  {
+    std::vector<int> stored(gsize, -10);
+    auto need = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 2 <= c; };
+    for (int t = 0; t < a->nops_fwd; ++t) {
+      const int k = a->fwd_kind[t], A = a->fwd_a[t], B = a->fwd_b[t], D = a->fwd_d[t], c = t / VM_CHUNK;
+      switch (k) {
+        case 0: if ((A >= 0 && !need(A, c)) || A < -1 || B < 0 || B >= a->cache_slots + 2) return bad("forward FMA op"); break;
+        case 2: if (!need(A, c) || !need(D, c)) return bad("forward FMAG op"); break;
+        case 5: if (!need(A, c) || D < 0 || D >= nnzL || B < -1 || B >= a->cache_slots) return bad("forward FINOFF op"); stored[D] = c; break;
+        case 6: if (D < 0 || D >= nnzL || B < 0 || B >= n) return bad("forward FINDIAG op"); stored[D] = c; stored[nnzL + B] = c; break;
+        case 7: if (D < 0 || D >= n) return bad("forward YSET op"); break;
+        case 8: if (D < nnzL + n || D >= gsize) return bad("forward FINY op"); stored[D] = c; break;
+        default: return bad("forward op kind");
+      }
+      if (t >= a->nops_fwd - 2 * VM_CHUNK && (k != 0 || B != a->cache_slots + 1)) return bad("forward stream tail (must be padding)");
+    }
+    std::fill(stored.begin(), stored.end(), -10);
+    for (int t = 0; t < a->nops_bwd; ++t) {
+      const int k = a->bwd_kind[t], A = a->bwd_a[t], B = a->bwd_b[t], D = a->bwd_d[t], c = t / VM_CHUNK;
+      switch (k) {
+        case 0: break;
+        case 1: if (!need(A, c) || !need(B, c)) return bad("backward WFMA op"); break;
+        case 3: if (!need(A, c)) return bad("backward WSET op"); break;
+        case 5: if (!need(A, c) || D < nnzL + n || D >= gsize) return bad("backward WFIN op"); stored[D] = c; break;
+        default: return bad("backward op kind");
+      }
+      if (t >= a->nops_bwd - 2 * VM_CHUNK && k != 0) return bad("backward stream tail (must be NOP padding)");
+    }
   }
   if (a->n_obs > 0) {
     if (a->obs_ptr[0] != 0) return bad("obs_ptr");
@@ -203,36 +211,28 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
 
   auto* h = new finrom_fom_s();
   FomDev& d = h->d;
-  d.n = n; d.nnzL = nnzL; d.npairs = a->npairs; d.xdim = a->xdim; d.n_obs = a->n_obs;
-  d.maxrow = 1;
+  d.n = n; d.nnzL = nnzL; d.xdim = a->xdim; d.n_obs = a->n_obs; d.n_alist = a->n_alist; d.cache_slots = a->cache_slots;
+  d.gsize = gsize;
+  d.nchunks_fwd = a->nops_fwd / VM_CHUNK - 2; d.nchunks_bwd = a->nops_bwd / VM_CHUNK - 2;
   d.debug_phases = 7;
   if (const char* ph = getenv("FINROM_FOM_PHASES")) d.debug_phases = atoi(ph);
-  for (int i = 0; i < n; ++i) d.maxrow = std::max(d.maxrow, a->row_ptr[i + 1] - a->row_ptr[i]);
-  std::vector<int> pair_mid(nnzL);
-  for (int i = 0; i < n; ++i)
-    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e) {
-      int q = a->pair_ptr[e];
-      while (q < a->pair_ptr[e + 1] && a->pair_a[q] - a->row_ptr[i] < FOM_ROW_CACHE) ++q;
-      for (int t = q; t < a->pair_ptr[e + 1]; ++t)
-        if (a->pair_a[t] - a->row_ptr[i] < FOM_ROW_CACHE) { delete h; set_error("fom_create: pair_a must ascend within an entry"); return FINROM_ERR_ARG; }
-      pair_mid[e] = q;
-    }
+  std::vector<int> fkb(a->nops_fwd), bkb(a->nops_bwd);
+  for (int t = 0; t < a->nops_fwd; ++t) fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8);
+  for (int t = 0; t < a->nops_bwd; ++t) bkb[t] = a->bwd_kind[t] | ((a->bwd_b[t] + 1) << 8);
   int rc = 0;
   const int nobsnz = a->n_obs > 0 ? a->obs_ptr[a->n_obs] : 0;
-  if (!rc) rc = up(h->owned, &d.row_ptr, a->row_ptr, n + 1);
-  if (!rc) rc = up(h->owned, &d.ent_col, a->ent_col, nnzL);
-  if (!rc) rc = up(h->owned, &d.pair_ptr, a->pair_ptr, nnzL + 1);
-  if (!rc) rc = up(h->owned, &d.pair_mid, pair_mid.data(), nnzL);
-  if (!rc) rc = up(h->owned, &d.pair_a, a->pair_a, a->npairs);
-  if (!rc) rc = up(h->owned, &d.pair_b, a->pair_b, a->npairs);
+  if (!rc) rc = up(h->owned, &d.a_list, a->a_list, a->n_alist);
   if (!rc) rc = up(h->owned, &d.asm_c0, a->asm_c0, nnzL);
   if (!rc) rc = up(h->owned, &d.asm_ptr, a->asm_ptr, nnzL + 1);
   if (!rc) rc = up(h->owned, &d.asm_idx, a->asm_idx, a->nasm);
   if (!rc) rc = up(h->owned, &d.asm_w, a->asm_w, a->nasm);
   if (!rc) rc = up(h->owned, &d.rhs, a->rhs, n);
-  if (!rc) rc = up(h->owned, &d.col_ptr, a->col_ptr, n + 1);
-  if (!rc) rc = up(h->owned, &d.col_ent, a->col_ent, nnzL - n);
-  if (!rc) rc = up(h->owned, &d.col_row, a->col_row, nnzL - n);
+  if (!rc) rc = up(h->owned, &d.f_a, a->fwd_a, a->nops_fwd);
+  if (!rc) rc = up(h->owned, &d.f_kb, fkb.data(), fkb.size());
+  if (!rc) rc = up(h->owned, &d.f_d, a->fwd_d, a->nops_fwd);
+  if (!rc) rc = up(h->owned, &d.b_a, a->bwd_a, a->nops_bwd);
+  if (!rc) rc = up(h->owned, &d.b_kb, bkb.data(), bkb.size());
+  if (!rc) rc = up(h->owned, &d.b_d, a->bwd_d, a->nops_bwd);
   if (!rc) rc = up(h->owned, &d.obs_ptr, a->obs_ptr, a->n_obs + 1);
   if (!rc) rc = up(h->owned, &d.obs_idx, a->obs_idx, nobsnz);
   if (!rc) rc = up(h->owned, &d.obs_w, a->obs_w, nobsnz);
@@ -245,7 +245,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
 void finrom_fom_destroy(finrom_fom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->xT.release(); h->Lw.release(); h->invd.release(); h->yw.release();
+  h->xT.release(); h->Gw.release();
   delete h;
 }
 
@@ -254,7 +254,7 @@ int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, do
   hipStream_t st = (hipStream_t)stream;
   const FomDev& d = h->d;
   // bound the per-call workspace (L values dominate: nnzL * 8 B per sample)
-  const size_t per_sample = ((size_t)d.nnzL + 2 * (size_t)d.n + d.xdim) * sizeof(double);
+  const size_t per_sample = ((size_t)d.gsize + d.xdim) * sizeof(double);
   int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
   chunk = std::max<int64_t>(64, chunk / 64 * 64);
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
@@ -262,13 +262,11 @@ int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, do
     const int64_t nblk = (Sc + 63) / 64;
     int rc;
     if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
-    if ((rc = h->Lw.reserve((size_t)nblk * d.nnzL * 64 * sizeof(double)))) return rc;
-    if ((rc = h->invd.reserve((size_t)nblk * d.n * 64 * sizeof(double)))) return rc;
-    if ((rc = h->yw.reserve((size_t)nblk * d.n * 64 * sizeof(double)))) return rc;
+    if ((rc = h->Gw.reserve((size_t)nblk * d.gsize * 64 * sizeof(double)))) return rc;
     if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
-    if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Lw.p, (double*)h->invd.p, (double*)h->yw.p,
+    if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Gw.p,
                          qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
-    if (w && (rc = launch_unpack_w(d, (const double*)h->yw.p, Sc, w + s0 * d.n, st))) return rc;
+    if (w && (rc = launch_unpack_w(d, (const double*)h->Gw.p, Sc, w + s0 * d.n, st))) return rc;
   }
   return 0;
 }

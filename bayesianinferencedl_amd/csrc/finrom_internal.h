@@ -9,7 +9,7 @@
 namespace finrom {
 
 constexpr int WAVE = 64;
-constexpr int FOM_ROW_CACHE = 36;   // LDS slots (512 B each) caching the row being eliminated: 18 KiB per wave, 7 waves per CU leave LDS for the ROM kernels
+constexpr int FOM_ROW_CACHE_UNUSED = 36;   // LDS slots (512 B each) caching the row being eliminated: 18 KiB per wave, 7 waves per CU leave LDS for the ROM kernels
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
@@ -56,18 +56,21 @@ struct Scratch {
 };
 
 // ---- FOM ------------------------------------------------------------------------------
+constexpr int VM_CHUNK = 16;        // ops whose global operands are fetched together, one chunk ahead
 struct FomDev {
   int debug_phases;   // bit 0 factor+forward, 1 backward, 2 QoI (FINROM_FOM_PHASES, timing experiments only; default 7)
-  int n, nnzL, npairs, xdim, n_obs, maxrow;   // maxrow = longest row of L (entries incl. diagonal)
-  const int* row_ptr; const int* ent_col; const int* pair_ptr; const int* pair_mid; const int* pair_a; const int* pair_b;
-  const double* asm_c0; const int* asm_ptr; const int* asm_idx; const double* asm_w;
-  const double* rhs; const int* col_ptr; const int* col_ent; const int* col_row;
+  int n, nnzL, xdim, n_obs, n_alist, cache_slots;
+  int gsize;                         // values per sample: nnzL + 2n  (L | 1/L_ii | y,w)
+  int nchunks_fwd, nchunks_bwd;      // executed chunks (the streams carry 2 more chunks of NOP padding)
+  const int* a_list; const double* asm_c0; const int* asm_ptr; const int* asm_idx; const double* asm_w;
+  const double* rhs;
+  const int* f_a; const int* f_kb; const int* f_d;     // forward stream: load index, kind | (b+1) << 8, d
+  const int* b_a; const int* b_kb; const int* b_d;     // backward stream
   const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
 };
 int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st);
-int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Lw, double* invd,
-               double* yw, double* qoi, int* info, hipStream_t st);
-int launch_unpack_w(const FomDev& p, const double* yw, int64_t S, double* w, hipStream_t st);
+int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st);
+int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st);
 
 // ---- ROM ------------------------------------------------------------------------------
 constexpr int ROM_MAX_PHASES = 8;

@@ -9,7 +9,10 @@
 // control flow and every index are wave-uniform (SGPRs, scalar loads), and each vector
 // memory access is one fully coalesced 512-byte line: element e of the wave's 64 samples
 // lives at  base + e*64 + lane  ("sample-blocked" layout [S/64][elements][64]).
-// Bound: HBM/L2 bandwidth (2 loads of 8 B per multiply-add, no reuse in registers).
+// The schedule is a flat op stream (bayesianinferencedl_amd/symbolic.py::build_op_streams)
+// interpreted by fom_vm_kernel; the "a" operand of a multiply-add comes from an LDS cache of the
+// row being eliminated, the "b" operand from global memory, fetched one 16-op chunk ahead.
+// Bound: HBM/L2 bandwidth (one 8-B load per multiply-add and sample, no reuse in registers).
 #include "finrom_internal.h"
 
 namespace finrom {
@@ -47,146 +50,181 @@ int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
-// fused FOM kernel, one wave per block of 64 samples
+// assembly pre-pass: G[e] = A_e(x) for every entry of L that carries a value of A
+// (fom :160-161 / rom :154-163).  Embarrassingly parallel, lane = sample, coalesced stores.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void fom_kernel(FomDev p, const double* __restrict__ xT, int64_t S,
-                                                 double* __restrict__ Lw, double* __restrict__ invd,
-                                                 double* __restrict__ yw, double* __restrict__ qoi,
-                                                 int* __restrict__ info) {
-  // LDS: the entries of the row being eliminated, [maxrow][64] (lane-private column of 8-B slots:
-  // conflict-free ds_read_b64 / ds_write_b64).  The "a" operand of every multiply-add is an entry
-  // of the current row, so only the "b" operand (an earlier row of L) comes from global memory.
-  extern __shared__ __attribute__((aligned(16))) double rowc[];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void fom_assemble_kernel(FomDev p, const int* __restrict__ a_list,
+                                                           const double* __restrict__ asm_c0, const int* __restrict__ asm_ptr,
+                                                           const int* __restrict__ asm_idx, const double* __restrict__ asm_w,
+                                                           const double* __restrict__ xT, double* __restrict__ Gw) {
+  const int lane = threadIdx.x & 63;
+  const int part = (threadIdx.x >> 6) + 4 * blockIdx.y, nparts = 4 * gridDim.y;
   const int64_t blk = blockIdx.x;
   const double* xb = xT + blk * (int64_t)p.xdim * 64 + lane;
-  double* Lb = Lw + blk * (int64_t)p.nnzL * 64 + lane;
-  double* ib = invd + blk * (int64_t)p.n * 64 + lane;
-  double* yb = yw + blk * (int64_t)p.n * 64 + lane;
+  double* G = Gw + blk * (int64_t)p.gsize * 64 + lane;
+  for (int t = part; t < p.n_alist; t += nparts) {
+    const int e = a_list[t];
+    const int t0 = asm_ptr[e], t1 = asm_ptr[e + 1];
+    double xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = xb[(int64_t)asm_idx[(t0 + u < t1) ? t0 + u : (t1 > t0 ? t1 - 1 : 0)] * 64];
+    double acc = asm_c0[e];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fma((t0 + u < t1) ? asm_w[t0 + u] : 0.0, xv[u], acc);
+    for (int q = t0 + 4; q < t1; ++q) acc = fma(asm_w[q], xb[(int64_t)asm_idx[q] * 64], acc);
+    G[(int64_t)e * 64] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// schedule interpreter: one wave per block of 64 samples executes the two op streams.
+// Global operands of chunk c+1 are in flight while chunk c executes (double-buffered in
+// registers); the op descriptors themselves are sequential scalar loads.
+// ---------------------------------------------------------------------------------------
+enum { F_FMA = 0, F_FMAG = 2, F_FINOFF = 5, F_FINDIAG = 6, F_YSET = 7, F_FINY = 8 };
+enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
+
+// The op arrays are separate __restrict__ kernel parameters on purpose: only then can the compiler
+// prove that the stores to G never clobber them and fetch the descriptors with SCALAR loads
+// (s_load_dwordx16); through the by-value struct they become vector loads + v_readfirstlane whose
+// s_waitcnt vmcnt(0) drains the operand prefetch on every op.
+__global__ __launch_bounds__(64) void fom_vm_kernel(FomDev p, const int* __restrict__ fA, const int* __restrict__ fKB,
+                                                    const int* __restrict__ fD, const int* __restrict__ bA,
+                                                    const int* __restrict__ bKB, const int* __restrict__ bD,
+                                                    const double* __restrict__ rhs, const int* __restrict__ obs_ptr,
+                                                    const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                    double* __restrict__ Gw, int64_t S,
+                                                    double* __restrict__ qoi, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double rowc[];   // [cache_slots + 2][64] row cache + 2 constants
+  const int lane = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  double* G = Gw + blk * (int64_t)p.gsize * 64 + lane;
   double* rc = rowc + lane;
+  rc[p.cache_slots * 64] = -1.0;          // NEG1 slot: "acc = A_e" is an FMA against it
+  rc[(p.cache_slots + 1) * 64] = 0.0;     // ZERO slot: padding ops
   int bad = 0;
+  double acc = 0.0, inv = 0.0;
 
-  // Every dependent global round trip costs ~1 us here (the wave has nothing else to do), so each
-  // entry issues ALL the loads it needs in one batch: up to 8 b-operands (predicated past the end of
-  // the list), the 1/L_jj it will be scaled by, and the first x values of its assembly.
-  // ---- numeric factorisation A = L L^T, row by row, fused with  L y = F ---------------
-  if (p.debug_phases & 1)
-  for (int i = 0; i < p.n; ++i) {
-    const int e0 = p.row_ptr[i], e1 = p.row_ptr[i + 1];
-    double inv_i = 0.0;
-    for (int e = e0; e < e1; ++e) {
-      int q = p.pair_ptr[e];
-      const int q1 = p.pair_mid[e], q2 = p.pair_ptr[e + 1];
-      const int t0 = p.asm_ptr[e], t1 = p.asm_ptr[e + 1];
-      const bool diag = (e == e1 - 1);
-      // one batch of loads
-      double lb[8], xv[4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) lb[u] = Lb[(int64_t)p.pair_b[(q + u < q1) ? q + u : (q1 > q ? q1 - 1 : 0)] * 64];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = xb[(int64_t)p.asm_idx[(t0 + u < t1) ? t0 + u : 0] * 64];
-      const double invj = diag ? 0.0 : ib[(int64_t)p.ent_col[e] * 64];
-      // affine assembly of A_e(x)            (fom :160-161 / rom :154-163)
-      double acc = p.asm_c0[e];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = fma((t0 + u < t1) ? p.asm_w[t0 + u] : 0.0, xv[u], acc);
-      for (int t = t0 + 4; t < t1; ++t) acc = fma(p.asm_w[t], xb[(int64_t)p.asm_idx[t] * 64], acc);
-      // acc -= sum_k L_ik L_jk : L_ik from the LDS row cache, L_jk from global
-      double acc2 = 0.0;
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) {
-        const double la0 = (q + u < q1) ? rc[(p.pair_a[q + u] - e0) * 64] : 0.0;
-        const double la1 = (q + u + 1 < q1) ? rc[(p.pair_a[q + u + 1] - e0) * 64] : 0.0;
-        acc = fma(-la0, lb[u], acc); acc2 = fma(-la1, lb[u + 1], acc2);
-      }
-      q += 8;
-      for (; q < q1; q += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) lb[u] = Lb[(int64_t)p.pair_b[(q + u < q1) ? q + u : q1 - 1] * 64];
-#pragma unroll
-        for (int u = 0; u < 8; u += 2) {
-          const double la0 = (q + u < q1) ? rc[(p.pair_a[q + u] - e0) * 64] : 0.0;
-          const double la1 = (q + u + 1 < q1) ? rc[(p.pair_a[q + u + 1] - e0) * 64] : 0.0;
-          acc = fma(-la0, lb[u], acc); acc2 = fma(-la1, lb[u + 1], acc2);
-        }
-      }
-      for (q = q1; q < q2; ++q)      // tail of very long rows: both operands from global
-        acc2 = fma(-Lb[(int64_t)p.pair_a[q] * 64], Lb[(int64_t)p.pair_b[q] * 64], acc2);
-      acc += acc2;
-      if (diag) {
-        bad |= !(acc > 0.0);
-        const double d = sqrt(acc);
-        inv_i = 1.0 / d;
-        Lb[(int64_t)e * 64] = d;
-        ib[(int64_t)i * 64] = inv_i;
-      } else {
-        const double l = acc * invj;
-        Lb[(int64_t)e * 64] = l;
-        if (e - e0 < FOM_ROW_CACHE) rc[(e - e0) * 64] = l;
-      }
-    }
-    // forward substitution row: y_i = (F_i - sum_k L_ik y_k) / L_ii, loads batched by 8
-    double yi = p.rhs[i], yi2 = 0.0;
-    for (int e = e0; e < e1 - 1; e += 8) {
-      double yv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) yv[u] = yb[(int64_t)p.ent_col[(e + u < e1 - 1) ? e + u : e1 - 2] * 64];
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) {
-        const int ea = e + u, eb = e + u + 1;
-        const double la = (ea < e1 - 1) ? ((ea - e0 < FOM_ROW_CACHE) ? rc[(ea - e0) * 64] : Lb[(int64_t)ea * 64]) : 0.0;
-        const double lc = (eb < e1 - 1) ? ((eb - e0 < FOM_ROW_CACHE) ? rc[(eb - e0) * 64] : Lb[(int64_t)eb * 64]) : 0.0;
-        yi = fma(-la, yv[u], yi); yi2 = fma(-lc, yv[u + 1], yi2);
-      }
-    }
-    yb[(int64_t)i * 64] = (yi + yi2) * inv_i;
+#define VM_LOAD1(buf, c)                                                      \
+  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
+    const int a_ = A[(c) * VM_CHUNK + u];                                     \
+    buf[u] = G[(int64_t)(a_ < 0 ? 0 : a_) * 64];                              \
   }
 
-  // ---- L^T w = y, in place (w overwrites y); loads batched by 8 -------------------------
-  if (p.debug_phases & 2)
-  for (int i = p.n - 1; i >= 0; --i) {
-    const int c0 = p.col_ptr[i], c1 = p.col_ptr[i + 1];
-    double wi = yb[(int64_t)i * 64], wi2 = 0.0;
-    const double invi = ib[(int64_t)i * 64];
-    for (int c = c0; c < c1; c += 8) {
-      double lv[8], wv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int cc = (c + u < c1) ? c + u : c1 - 1;
-        lv[u] = Lb[(int64_t)p.col_ent[cc] * 64];
-        wv[u] = yb[(int64_t)p.col_row[cc] * 64];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) {
-        wi = fma((c + u < c1) ? -lv[u] : 0.0, wv[u], wi);
-        wi2 = fma((c + u + 1 < c1) ? -lv[u + 1] : 0.0, wv[u + 1], wi2);
-      }
+  // ---- forward: numeric factorisation A = L L^T fused with L y = F -------------------
+  if (p.debug_phases & 1) {
+    const int* __restrict__ A = fA; const int* __restrict__ KB = fKB; const int* __restrict__ D = fD;
+    double bufA[VM_CHUNK], bufB[VM_CHUNK];
+#define VM_EXEC_F(buf, c)                                                     \
+  int kbv[VM_CHUNK], dv[VM_CHUNK];   /* descriptors of the whole chunk: two s_load_dwordx16 */ \
+  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = KB[(c) * VM_CHUNK + u]; dv[u] = D[(c) * VM_CHUNK + u]; } \
+  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
+    const int kb = kbv[u];                                                    \
+    const int kind = kb & 255, b = (kb >> 8) - 1;                             \
+    const double ld = buf[u];                                                 \
+    if (__builtin_expect(kind == F_FMA, 1)) {                                 \
+      acc = fma(-rc[b * 64], ld, acc);   /* also "acc = A_e" (NEG1 slot) and padding (ZERO slot) */ \
+    } else {                                                                  \
+      const int d = dv[u];                                                    \
+      switch (kind) {                                                         \
+        case F_FMAG: acc = fma(-G[(int64_t)d * 64], ld, acc); break;          \
+        case F_FINOFF: {                                                      \
+          const double l = acc * ld;                                          \
+          G[(int64_t)d * 64] = l;                                             \
+          if (b >= 0) rc[b * 64] = l;                                         \
+          acc = 0.0;                                                          \
+        } break;                                                              \
+        case F_FINDIAG: {                                                     \
+          bad |= !(acc > 0.0);                                                \
+          const double t = sqrt(acc);                                         \
+          inv = 1.0 / t;                                                      \
+          G[(int64_t)d * 64] = t;                                             \
+          G[(int64_t)(p.nnzL + b) * 64] = inv;                                \
+          acc = 0.0;                                                          \
+        } break;                                                              \
+        case F_YSET: acc = rhs[d]; break;                                     \
+        case F_FINY: G[(int64_t)d * 64] = acc * inv; acc = 0.0; break;        \
+        default: break;                                                       \
+      }                                                                       \
+    }                                                                         \
+  }
+    VM_LOAD1(bufA, 0)
+    for (int c = 0; c < p.nchunks_fwd; c += 2) {
+      VM_LOAD1(bufB, c + 1)
+      { VM_EXEC_F(bufA, c) }
+      VM_LOAD1(bufA, c + 2)
+      { VM_EXEC_F(bufB, c + 1) }
     }
-    yb[(int64_t)i * 64] = (wi + wi2) * invi;
+#undef VM_EXEC_F
   }
 
-  // ---- QoI = B_obs w  (fom :408-412) ---------------------------------------------------
+  // ---- backward: L^T w = y, w overwrites y ----------------------------------------------
+  if (p.debug_phases & 2) {
+    const int* __restrict__ A = bA; const int* __restrict__ KB = bKB; const int* __restrict__ D = bD;
+    double a1[VM_CHUNK], b1[VM_CHUNK], a2[VM_CHUNK], b2[VM_CHUNK];
+#define VM_LOAD2(bufa, bufb, c)                                               \
+  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
+    const int a_ = A[(c) * VM_CHUNK + u];                                     \
+    const int b_ = (KB[(c) * VM_CHUNK + u] >> 8) - 1;                         \
+    bufa[u] = G[(int64_t)(a_ < 0 ? 0 : a_) * 64];                             \
+    bufb[u] = G[(int64_t)(b_ < 0 ? 0 : b_) * 64];                             \
+  }
+#define VM_EXEC_B(bufa, bufb, c)                                              \
+  int kbv[VM_CHUNK], dv[VM_CHUNK];                                            \
+  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = KB[(c) * VM_CHUNK + u]; dv[u] = D[(c) * VM_CHUNK + u]; } \
+  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
+    const int kind = kbv[u] & 255;                                            \
+    if (kind == B_WFMA) acc = fma(-bufa[u], bufb[u], acc);                    \
+    else if (kind == B_WSET) acc = bufa[u];                                   \
+    else if (kind == B_WFIN) G[(int64_t)dv[u] * 64] = acc * bufa[u];          \
+  }
+    VM_LOAD2(a1, b1, 0)
+    for (int c = 0; c < p.nchunks_bwd; c += 2) {
+      VM_LOAD2(a2, b2, c + 1)
+      { VM_EXEC_B(a1, b1, c) }
+      VM_LOAD2(a1, b1, c + 2)
+      { VM_EXEC_B(a2, b2, c + 1) }
+    }
+#undef VM_EXEC_B
+#undef VM_LOAD2
+  }
+#undef VM_LOAD1
+
+  // ---- QoI = B_obs w  (fom :408-412), loads batched by 8 -------------------------------
   const int64_t s = blk * 64 + lane;
   const double nanv = __builtin_nan("");
+  const double* wv = G + (int64_t)(p.nnzL + p.n) * 64;
   if (p.debug_phases & 4)
   for (int o = 0; o < p.n_obs; ++o) {
-    double qv = 0.0;
-    for (int t = p.obs_ptr[o], t1 = p.obs_ptr[o + 1]; t < t1; ++t)
-      qv = fma(p.obs_w[t], yb[(int64_t)p.obs_idx[t] * 64], qv);
-    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : qv;
+    double q0 = 0.0, q1 = 0.0;
+    const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
+    for (int t = t0; t < t1; t += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = wv[(int64_t)obs_idx[(t + u < t1) ? t + u : t1 - 1] * 64];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        q0 = fma((t + u < t1) ? obs_w[t + u] : 0.0, v[u], q0);
+        q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
+      }
+    }
+    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : (q0 + q1);
   }
   if (bad)
-    for (int i = 0; i < p.n; ++i) yb[(int64_t)i * 64] = nanv;
+    for (int i = 0; i < p.n; ++i) G[(int64_t)(p.nnzL + p.n + i) * 64] = nanv;
   if (info != nullptr && s < S && bad) atomicOr(&info[s], 1);   // the ROM half may set bit 1 concurrently
 }
 
-int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Lw, double* invd,
-               double* yw, double* qoi, int* info, hipStream_t st) {
+int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info,
+               hipStream_t st) {
   if (nblk == 0) return 0;
   ScopedKernelTimer t(K_FOM, st);
-  // 36 slots x 512 B = 18 KiB per wave: 7 waves per CU (1792 resident waves >= 1563 for 100k samples)
-  const size_t lds = (size_t)(p.maxrow < FOM_ROW_CACHE ? p.maxrow : FOM_ROW_CACHE) * 64 * sizeof(double);
-  hipLaunchKernelGGL(fom_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, xT, S, Lw, invd, yw, qoi, info);
+  hipLaunchKernelGGL(fom_assemble_kernel, dim3((unsigned)nblk, 4), dim3(256), 0, st, p, p.a_list, p.asm_c0, p.asm_ptr, p.asm_idx,
+                     p.asm_w, xT, Gw);
+  FR_HIP(hipGetLastError());
+  const size_t lds = (size_t)(p.cache_slots + 2) * 64 * sizeof(double);
+  hipLaunchKernelGGL(fom_vm_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.b_a, p.b_kb, p.b_d,
+                     p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, Gw, S, qoi, info);
   FR_HIP(hipGetLastError());
   return 0;
 }
@@ -194,15 +232,15 @@ int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, doubl
 // ---------------------------------------------------------------------------------------
 // unpack: blocked, permuted w -> row-major w[S][n] in the caller's dof order
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void unpack_w_kernel(const double* __restrict__ yw, const int* __restrict__ perm,
-                                                       int n, int64_t S, double* __restrict__ w) {
+__global__ __launch_bounds__(256) void unpack_w_kernel(const double* __restrict__ Gw, const int* __restrict__ perm,
+                                                       int n, int gsize, int woff, int64_t S, double* __restrict__ w) {
   __shared__ double tile[64][65];
   const int64_t blk = blockIdx.x;
   const int i0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int il = ty; il < 64; il += 4) {
     int i = i0 + il;
-    tile[il][tx] = (i < n) ? yw[(blk * n + i) * 64 + tx] : 0.0;
+    tile[il][tx] = (i < n) ? Gw[(blk * gsize + woff + i) * 64 + tx] : 0.0;
   }
   __syncthreads();
   const int i = i0 + tx;
@@ -213,12 +251,12 @@ __global__ __launch_bounds__(256) void unpack_w_kernel(const double* __restrict_
   }
 }
 
-int launch_unpack_w(const FomDev& p, const double* yw, int64_t S, double* w, hipStream_t st) {
+int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st) {
   int64_t nblk = (S + 63) / 64;
   if (nblk == 0) return 0;
   ScopedKernelTimer t(K_UNPACK_W, st);
   dim3 grid((unsigned)nblk, (unsigned)((p.n + 63) / 64));
-  hipLaunchKernelGGL(unpack_w_kernel, grid, dim3(256), 0, st, yw, p.perm, p.n, S, w);
+  hipLaunchKernelGGL(unpack_w_kernel, grid, dim3(256), 0, st, Gw, p.perm, p.n, p.gsize, p.nnzL + p.n, S, w);
   FR_HIP(hipGetLastError());
   return 0;
 }

@@ -13,6 +13,9 @@ from . import _ffi
 from ._ffi import DeviceBuffer, FomDesc, RomDesc, check, f64, i32, lib
 
 
+ROW_CACHE_SLOTS = 36     # LDS row cache of the FOM interpreter: 18 KiB per wave, 7 waves per CU
+
+
 def _is_torch(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
@@ -83,12 +86,15 @@ class FomEngine:
         def D(a):
             a, p = f64(a); keep.append(a); return p
 
-        d = FomDesc(n=plan.n, nnzL=plan.nnzL, npairs=plan.npairs, xdim=self.xdim, n_obs=self.n_obs, nasm=len(aidx),
-                    row_ptr=I(plan.row_ptr), ent_col=I(plan.ent_col), pair_ptr=I(plan.pair_ptr),
-                    pair_a=I(plan.pair_a), pair_b=I(plan.pair_b), asm_c0=D(c0), asm_ptr=I(aptr),
-                    asm_idx=I(aidx), asm_w=D(aw), rhs=D(np.asarray(rhs)[plan.perm]), col_ptr=I(plan.col_ptr),
-                    col_ent=I(plan.col_ent), col_row=I(plan.col_row), obs_ptr=I(optr), obs_idx=I(oidx),
-                    obs_w=D(ow), perm=I(plan.perm))
+        streams = plan.op_streams(ROW_CACHE_SLOTS, np.asarray(rhs)[plan.perm])
+        fk, fa, fb, fd = streams["fwd"]; bk, ba, bb, bd = streams["bwd"]
+        d = FomDesc(n=plan.n, nnzL=plan.nnzL, xdim=self.xdim, n_obs=self.n_obs, nasm=len(aidx),
+                    n_alist=len(streams["a_list"]), cache_slots=ROW_CACHE_SLOTS, nops_fwd=len(fk), nops_bwd=len(bk),
+                    a_list=I(streams["a_list"]), asm_c0=D(c0), asm_ptr=I(aptr), asm_idx=I(aidx), asm_w=D(aw),
+                    rhs=D(np.asarray(rhs)[plan.perm]),
+                    fwd_kind=I(fk), fwd_a=I(fa), fwd_b=I(fb), fwd_d=I(fd),
+                    bwd_kind=I(bk), bwd_a=I(ba), bwd_b=I(bb), bwd_d=I(bd),
+                    obs_ptr=I(optr), obs_idx=I(oidx), obs_w=D(ow), perm=I(plan.perm))
         h = C.c_void_p()
         check(lib().finrom_fom_create(C.byref(d), C.byref(h)), "finrom_fom_create")
         self._h = h

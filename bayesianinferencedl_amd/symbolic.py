@@ -219,6 +219,15 @@ class CholeskyPlan:
         cc = np.diff(self.col_ptr).astype(np.int64) + 1
         return int((cc * cc).sum())
 
+    def op_streams(self, cache_slots, rhs_perm=None):
+        """Op streams of the device interpreter (cached per cache size and load pattern)."""
+        nz = None if rhs_perm is None else (np.asarray(rhs_perm) != 0.0)
+        key = (cache_slots, None if nz is None else nz.tobytes())
+        cache = self.__dict__.setdefault("_streams", {})
+        if key not in cache:
+            cache[key] = build_op_streams(self, cache_slots, nz)
+        return cache[key]
+
     def entry_table(self, c0_csr, W_csr):
         """Re-index a sparse-affine value map ``vals = c0 + W @ x`` (defined on the CSR
         pattern of A) onto the entries of L: returns (c0[nnzL], ptr[nnzL+1], idx, w)."""
@@ -235,3 +244,228 @@ class CholeskyPlan:
             idx[ptr[e]:ptr[e + 1]] = W_csr.indices[sl]
             w[ptr[e]:ptr[e + 1]] = W_csr.data[sl]
         return c0, ptr.astype(np.int32), idx, w
+
+
+# =========================================================================================
+# Op streams for the device "schedule interpreter" (csrc/fom_kernels.hip::fom_vm_kernel)
+# =========================================================================================
+# The factorisation / substitution schedule is flattened into a stream of fixed-size ops that a
+# wave executes for its 64 samples.  The wave fetches the ops' global operands one CHUNK (16 ops)
+# ahead of executing them, so a value stored while chunk c executes may be fetched no earlier than
+# for chunk c+2.  This module orders the rows (any topological order of the elimination tree is a
+# valid elimination order) and pads with NOPs so that rule always holds; tests/test_host_and_abi.py
+# replays the stream with exactly that prefetch semantics.
+#
+# Per-sample value space G (doubles):  [0, nnzL) entries of L (initially the assembled A values),
+# [nnzL, nnzL+n) 1/L_ii,  [nnzL+n, nnzL+2n) y then w.
+CHUNK = 16
+# forward kinds.  Kind 0 is the only common one and is branch-free on the device:
+#   acc -= rc[b] * G[a]        with two constant LDS slots after the row cache: NEG1 (-1.0) and ZERO (0.0),
+# so "acc = A_e" is an FMA against NEG1 (every FIN* op leaves acc = 0) and padding is an FMA against ZERO.
+OP_FMA, OP_FMAG, OP_FINOFF, OP_FINDIAG, OP_YSET, OP_FINY = 0, 2, 5, 6, 7, 8
+OPB_NOP, OPB_WFMA, OPB_WSET, OPB_WFIN = 0, 1, 3, 5
+
+
+class _Emitter:
+    def __init__(self, nvals, pad_b=-1):
+        self.pad_b = pad_b                                   # b field of padding ops (forward: the ZERO slot)
+        self.kind, self.a, self.b, self.d = [], [], [], []
+        self.store_chunk = np.full(nvals, -10, np.int64)     # chunk in which a value was last stored
+
+    def pos(self):
+        return len(self.kind)
+
+    def emit(self, kind, a=-1, b=-1, d=-1, loads=(), stores=()):
+        need = 0
+        for g in loads:
+            need = max(need, (self.store_chunk[g] + 2) * CHUNK)
+        while self.pos() < need:
+            self.kind.append(0); self.a.append(-1); self.b.append(self.pad_b); self.d.append(-1)
+        c = self.pos() // CHUNK
+        self.kind.append(kind); self.a.append(a); self.b.append(b); self.d.append(d)
+        for g in stores:
+            self.store_chunk[g] = c
+
+    def arrays(self):
+        n = self.pos()
+        pad = (-n) % (2 * CHUNK) + 2 * CHUNK          # whole number of chunk pairs + one spare pair
+        k = np.asarray(self.kind + [0] * pad, np.int32)
+        a = np.asarray(self.a + [-1] * pad, np.int32)
+        b = np.asarray(self.b + [self.pad_b] * pad, np.int32)
+        d = np.asarray(self.d + [-1] * pad, np.int32)
+        return k, a, b, d
+
+
+def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
+    """-> dict(fwd=(kind, a, b, d), bwd=(kind, a, b, d), a_list=entries of L that carry an A value).
+    rhs_nonzero[i] (permuted order): rows whose load F_i may be non-zero (None = all)."""
+    n, nnzL = plan.n, plan.nnzL
+    row_ptr, ent_col = plan.row_ptr.astype(np.int64), plan.ent_col.astype(np.int64)
+    pair_ptr = plan.pair_ptr.astype(np.int64)
+    IV, YV = nnzL, nnzL + n
+    rows_cols = [ent_col[row_ptr[i]:row_ptr[i + 1] - 1] for i in range(n)]
+    # children lists by direct dependency: row i needs every row j in its structure
+    ndeps = np.array([len(c) for c in rows_cols])
+    users = [[] for _ in range(n)]
+    for i in range(n):
+        for j in rows_cols[i]:
+            users[j].append(i)
+    # priority = longest remaining chain to the root of the elimination tree
+    height = np.zeros(n, np.int64)
+    for i in range(n - 1, -1, -1):
+        par = plan.parent[i]
+        height[i] = 0 if par < 0 else height[par] + (row_ptr[par + 1] - row_ptr[par])
+    import heapq
+
+    # ---------------- forward: factorisation + L y = F -----------------------------------
+    NEG1, ZERO = cache_slots, cache_slots + 1
+    em = _Emitter(nnzL + 2 * n, pad_b=ZERO)
+    done_chunk = np.zeros(n, np.int64)
+    remaining = ndeps.copy()
+    eligible = [(-height[i], i) for i in range(n) if remaining[i] == 0]
+    heapq.heapify(eligible)
+    waiting = []          # (ready_chunk, -height, i): eligible but would need padding right now
+    order = []
+    while eligible or waiting:
+        cur = em.pos() // CHUNK
+        while waiting and waiting[0][0] <= cur:
+            _, nh, i = heapq.heappop(waiting)
+            heapq.heappush(eligible, (nh, i))
+        if eligible:
+            _, i = heapq.heappop(eligible)
+            ready = max([done_chunk[j] + 2 for j in rows_cols[i]], default=0)
+            if ready > cur and (eligible or (waiting and waiting[0][0] < ready)):
+                heapq.heappush(waiting, (ready, -height[i], i))
+                continue
+        else:
+            _, _, i = heapq.heappop(waiting)
+        order.append(i)
+        e0, e1 = row_ptr[i], row_ptr[i + 1]
+        for e in range(e0, e1):
+            j = ent_col[e]
+            if plan.a_ent[e] >= 0:
+                em.emit(OP_FMA, a=e, b=NEG1, loads=(e,))              # acc = 0 - (-1) * A_e
+            for q in range(pair_ptr[e], pair_ptr[e + 1]):
+                pa, pb = int(plan.pair_a[q]), int(plan.pair_b[q])
+                slot = pa - e0
+                if slot < cache_slots:
+                    em.emit(OP_FMA, a=pb, b=slot, loads=(pb,))
+                else:
+                    em.emit(OP_FMAG, a=pb, d=pa, loads=(pb, pa))
+            if e == e1 - 1:
+                em.emit(OP_FINDIAG, b=i, d=e, stores=(e, IV + i))
+            else:
+                slot = e - e0
+                em.emit(OP_FINOFF, a=IV + j, b=slot if slot < cache_slots else -1, d=e, loads=(IV + j,), stores=(e,))
+        if rhs_nonzero is None or rhs_nonzero[i]:
+            em.emit(OP_YSET, d=i)
+        for e in range(e0, e1 - 1):
+            slot = e - e0
+            yk = YV + ent_col[e]
+            if slot < cache_slots:
+                em.emit(OP_FMA, a=yk, b=slot, loads=(yk,))
+            else:
+                em.emit(OP_FMAG, a=yk, d=e, loads=(yk, e))
+        em.emit(OP_FINY, d=YV + i, stores=(YV + i,))
+        done_chunk[i] = (em.pos() - 1) // CHUNK
+        for u in users[i]:
+            remaining[u] -= 1
+            if remaining[u] == 0:
+                heapq.heappush(eligible, (-height[u], u))
+    assert len(order) == n
+    fwd = em.arrays()
+
+    # ---------------- backward: L^T w = y (w overwrites y) --------------------------------
+    col_ptr = plan.col_ptr.astype(np.int64)
+    emb = _Emitter(nnzL + 2 * n)
+    ndeps_b = np.diff(col_ptr)
+    users_b = [[] for _ in range(n)]
+    for i in range(n):
+        for c in range(col_ptr[i], col_ptr[i + 1]):
+            users_b[plan.col_row[c]].append(i)
+    depth = np.zeros(n, np.int64)             # longest chain towards the leaves
+    for i in range(n):
+        par = plan.parent[i]
+        if par >= 0:
+            depth[par] = max(depth[par], depth[i] + 1 + (col_ptr[i + 1] - col_ptr[i]))
+    done_b = np.zeros(n, np.int64)
+    remaining = ndeps_b.copy()
+    eligible = [(-depth[i], i) for i in range(n) if remaining[i] == 0]
+    heapq.heapify(eligible)
+    waiting = []
+    cnt = 0
+    while eligible or waiting:
+        cur = emb.pos() // CHUNK
+        while waiting and waiting[0][0] <= cur:
+            _, nh, i = heapq.heappop(waiting)
+            heapq.heappush(eligible, (nh, i))
+        if eligible:
+            _, i = heapq.heappop(eligible)
+            ready = max([done_b[plan.col_row[c]] + 2 for c in range(col_ptr[i], col_ptr[i + 1])], default=0)
+            if ready > cur and (eligible or (waiting and waiting[0][0] < ready)):
+                heapq.heappush(waiting, (ready, -depth[i], i))
+                continue
+        else:
+            _, _, i = heapq.heappop(waiting)
+        cnt += 1
+        emb.emit(OPB_WSET, a=YV + i, loads=(YV + i,))
+        for c in range(col_ptr[i], col_ptr[i + 1]):
+            le, wr = int(plan.col_ent[c]), YV + int(plan.col_row[c])
+            emb.emit(OPB_WFMA, a=le, b=wr, loads=(wr,))
+        emb.emit(OPB_WFIN, a=IV + i, d=YV + i, stores=(YV + i,))
+        done_b[i] = (emb.pos() - 1) // CHUNK
+        for u in users_b[i]:
+            remaining[u] -= 1
+            if remaining[u] == 0:
+                heapq.heappush(eligible, (-depth[u], u))
+    assert cnt == n
+    bwd = emb.arrays()
+    a_list = np.nonzero(plan.a_ent >= 0)[0].astype(np.int32)
+    return {"fwd": fwd, "bwd": bwd, "a_list": a_list}
+
+
+def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
+    """NumPy replay of the device interpreter WITH its prefetch semantics (operands of chunk c+1 are
+    read before chunk c executes); A_entries[e] = assembled A value of entry e (0 for fill).
+    Returns w in the permuted dof order."""
+    n, nnzL = plan.n, plan.nnzL
+    G = np.zeros(nnzL + 2 * n)
+    G[:nnzL] = A_entries
+    rc = np.zeros(cache_slots + 2); rc[cache_slots] = -1.0
+
+    def run(stream, backward):
+        kind, a, b, d = stream
+        nch = len(kind) // CHUNK
+        acc = 0.0
+        inv = 0.0
+
+        def fetch(c):
+            if c >= nch:
+                return None
+            sl = slice(c * CHUNK, (c + 1) * CHUNK)
+            va = G[np.maximum(a[sl], 0)].copy()
+            vb = G[np.maximum(b[sl], 0)].copy() if backward else None
+            return va, vb
+        nxt = fetch(0)
+        for c in range(nch):
+            cur, nxt = nxt, fetch(c + 1)            # chunk c+1 is fetched BEFORE chunk c executes
+            for u in range(CHUNK):
+                t = c * CHUNK + u
+                k, ld = kind[t], cur[0][u]
+                if backward:
+                    if k == OPB_WSET: acc = ld
+                    elif k == OPB_WFMA: acc -= ld * cur[1][u]
+                    elif k == OPB_WFIN: G[d[t]] = acc * ld
+                else:
+                    if k == OP_FMA: acc -= rc[b[t]] * ld
+                    elif k == OP_FMAG: acc -= G[d[t]] * ld
+                    elif k == OP_FINOFF:
+                        l = acc * ld; G[d[t]] = l; acc = 0.0
+                        if b[t] >= 0: rc[b[t]] = l
+                    elif k == OP_FINDIAG:
+                        dd = np.sqrt(acc); inv = 1.0 / dd; G[d[t]] = dd; G[nnzL + b[t]] = inv; acc = 0.0
+                    elif k == OP_YSET: acc = rhs_perm[d[t]]
+                    elif k == OP_FINY: G[d[t]] = acc * inv; acc = 0.0
+    run(streams["fwd"], False)
+    run(streams["bwd"], True)
+    return G[nnzL + n:].copy()

@@ -79,27 +79,40 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
  *   x = 9 sub-fin averages             sum_i x_i A_i + Bi M                        rom :154-163
  * The symbolic phase (ordering, pattern of L, elimination schedule) is done once on the
  * host (bayesianinferencedl_amd/symbolic.py); all arrays are in the PERMUTED dof order.
+ *
+ * The numeric phase is a schedule interpreter: per sample it keeps a value vector
+ *   G = [ L entries (nnzL, initially the assembled A_e) | 1/L_ii (n) | y, then w (n) ]
+ * and executes two op streams (factorisation + L y = F, then L^T w = y).  A wave (64 samples,
+ * lane = sample) fetches the global operands of chunk c+1 (16 ops) before it executes chunk c,
+ * so the host must order/pad the streams such that a value stored in chunk c is not loaded
+ * before chunk c+2 (checked at create).  Ops (kind, a, b, d), acc = per-sample accumulator,
+ * rc = the LDS cache of the row being eliminated (cache_slots entries):
+ *   forward  0 FMA acc -= rc[b]*G[a]   (rc[cache_slots] == -1 and rc[cache_slots+1] == 0 are constants:
+ *                  "acc = A_e" is an FMA against the first, padding an FMA against the second with a = -1)
+ *            2 FMAG acc -= G[d]*G[a]
+ *            5 FINOFF l = acc*G[a]; G[d] = l; if b >= 0: rc[b] = l; acc = 0
+ *            6 FINDIAG t = sqrt(acc); G[d] = t; G[nnzL+b] = inv = 1/t; acc = 0 (acc <= 0 flags the sample)
+ *            7 YSET acc = rhs[d] | 8 FINY G[d] = acc*inv; acc = 0
+ *   backward 0 NOP | 1 WFMA acc -= G[a]*G[b] | 3 WSET acc = G[a] | 5 WFIN G[d] = acc*G[a]
  */
 typedef struct {
   int32_t n;               /* dofs */
-  int32_t nnzL;            /* entries of L, row-major, diagonal last in each row */
-  int32_t npairs;          /* multiply-adds of the factorisation schedule */
+  int32_t nnzL;            /* entries of L */
   int32_t xdim;            /* length of one parameter vector x */
   int32_t n_obs;           /* rows of the observation operator */
   int32_t nasm;            /* entries of asm_idx / asm_w */
-  const int32_t* row_ptr;  /* [n+1]  */
-  const int32_t* ent_col;  /* [nnzL] */
-  const int32_t* pair_ptr; /* [nnzL+1] */
-  const int32_t* pair_a;   /* [npairs] */
-  const int32_t* pair_b;   /* [npairs] */
+  int32_t n_alist;         /* entries of L that carry a value of A */
+  int32_t cache_slots;     /* LDS row-cache slots the forward stream assumes (1..64) */
+  int32_t nops_fwd;        /* multiple of 32, the last 32 ops are padding */
+  int32_t nops_bwd;        /* same */
+  const int32_t* a_list;   /* [n_alist] entry indices, ascending */
   const double*  asm_c0;   /* [nnzL] */
   const int32_t* asm_ptr;  /* [nnzL+1] */
   const int32_t* asm_idx;  /* [nasm] */
   const double*  asm_w;    /* [nasm] */
   const double*  rhs;      /* [n]   load vector F (fom :162-163), permuted */
-  const int32_t* col_ptr;  /* [n+1]  strictly-lower entries of each column of L */
-  const int32_t* col_ent;  /* [nnzL-n] */
-  const int32_t* col_row;  /* [nnzL-n] */
+  const int32_t* fwd_kind; const int32_t* fwd_a; const int32_t* fwd_b; const int32_t* fwd_d;   /* [nops_fwd] each */
+  const int32_t* bwd_kind; const int32_t* bwd_a; const int32_t* bwd_b; const int32_t* bwd_d;   /* [nops_bwd] each */
   const int32_t* obs_ptr;  /* [n_obs+1]  CSR of B_obs (fom :215-231) over permuted dofs */
   const int32_t* obs_idx;
   const double*  obs_w;

@@ -93,6 +93,31 @@ def test_cholesky_plan_schedule_reproduces_the_solve(spaces, ordering):
     assert plan.npairs == sum(len(a) for a in [plan.pair_a])
 
 
+@pytest.mark.parametrize("m,cache", [(4, 36), (4, 3), (12, 36)])
+def test_op_streams_replay_with_prefetch_semantics(spaces, m, cache):
+    """The device interpreter fetches the operands of chunk c+1 before executing chunk c; the
+    NumPy replay does the same, so a scheduling/padding bug shows up as a wrong solution."""
+    from bayesianinferencedl_amd.symbolic import CholeskyPlan, build_op_streams, replay_op_streams, CHUNK
+    ops = spaces(m).operators()
+    plan = CholeskyPlan(ops.indptr, ops.indices, ops.n)
+    st = build_op_streams(plan, cache)
+    for name in ("fwd", "bwd"):
+        k = st[name][0]
+        assert len(k) % (2 * CHUNK) == 0 and (k[-2 * CHUNK:] == 0).all()
+    rng = np.random.default_rng(2)
+    kf = np.exp(0.3 * rng.standard_normal(ops.n))
+    vals = ops.fom_values(kf)
+    Aent = np.zeros(plan.nnzL); has = plan.a_ent >= 0; Aent[has] = vals[plan.a_ent[has]]
+    wp = replay_op_streams(plan, st, Aent, ops.F[plan.perm], cache)
+    w = np.empty(ops.n); w[plan.perm] = wp
+    ref = spl.spsolve(ops.csr(vals).tocsc(), ops.F)
+    assert np.linalg.norm(w - ref) < 1e-12 * np.linalg.norm(ref)
+    k, a, b, d = st["fwd"]
+    real = ((k != 0) | (b != cache + 1)).sum()            # everything but the ZERO-slot padding
+    n_a = (plan.a_ent >= 0).sum()
+    assert real == n_a + plan.npairs + plan.nnzL + (plan.nnzL - ops.n) + 2 * ops.n
+
+
 def test_function_space_shim(spaces):
     from bayesianinferencedl_amd.fem import Function
     V = spaces(4)
