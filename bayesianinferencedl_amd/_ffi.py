@@ -49,6 +49,7 @@ SIGNATURES = {
     "finrom_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
     "finrom_stream_sync": (C.c_int, [C.c_void_p]),
     "finrom_profile_enable": (C.c_int, [C.c_int]),
+    "finrom_set_overlap": (C.c_int, [C.c_int]),
     "finrom_profile_reset": (C.c_int, []),
     "finrom_profile_slots": (C.c_int, []),
     "finrom_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

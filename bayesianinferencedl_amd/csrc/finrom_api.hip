@@ -33,6 +33,7 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<Pending> g_pending;
 static std::vector<hipEvent_t> g_pool;
+static bool g_overlap = true;
 static double g_ms[K_NUM];
 static int64_t g_cnt[K_NUM];
 
@@ -132,6 +133,7 @@ int finrom_memset(void* dst, int value, size_t bytes, void* stream) {
 }
 int finrom_stream_sync(void* stream) { FR_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 
+int finrom_set_overlap(int on) { g_overlap = on != 0; return 0; }
 int finrom_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_on = on != 0; return 0; }
 int finrom_profile_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -415,7 +417,7 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     if ((rc = rom->theta.reserve((size_t)S * rom->d.P * sizeof(double)))) return rc;
     theta = (double*)rom->theta.p;
   }
-  static const bool overlap = getenv("FINROM_NO_OVERLAP") == nullptr;   // serial mode: per-kernel profiling
+  const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr;   // serial mode: per-kernel profiling
   hipStream_t side = overlap ? rom->side : st;
   // fork: everything already queued on the caller's stream (inputs, zeroed info) precedes both halves
   if (overlap) {

@@ -122,6 +122,16 @@ def main():
         res = step()
     fence()
     L = _ffi.lib()
+    # context only (NOT the timed region): one pass with the two halves serialised on one stream gives
+    # each kernel's stand-alone duration; in the timed region the FOM and ROM kernels overlap
+    serial_ms = None
+    if not args.no_profile:
+        L.finrom_profile_reset(); L.finrom_profile_enable(1)
+        L.finrom_set_overlap(0)
+        step(); fence()
+        L.finrom_set_overlap(1)
+        L.finrom_profile_enable(0)
+        serial_ms = {k: round(v[1] / v[0], 4) for k, v in _ffi.profile_read().items() if v[0]}
     L.finrom_profile_reset()
     L.finrom_profile_enable(0 if args.no_profile else 1)
     t0 = time.perf_counter()
@@ -147,18 +157,24 @@ def main():
         cand = {k: v[1] for k, v in prof.items()}
         dom = max(cand, key=cand.get) if any(cand.values()) else "rom_proj_mfma"
         roof = None
+        traffic = measured_traffic(dom)
         if dom == "rom_proj_mfma" and ms[dom] > 0:
             alg = S * (fl["syrk_sym"] + 2 * solver_r._rom.nterms * args.r + fl["rhs"])
             ach = alg / (ms[dom] * 1e-3) / 1e12
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
                     "algorithmic_flops_per_launch": alg, "avg_launch_ms": ms[dom]}
         elif ms.get(dom, 0) > 0:
-            # FOM kernel: the factor is streamed (written once, read once by the back substitution)
-            alg = S * 8 * (2 * plan.nnzL + 4 * ops.n + pairs.xdim + pairs.n_obs)
+            # FOM interpreter: per sample one 8-B operand per multiply-add of the schedule
+            # (the other operand sits in LDS), L / 1/L_ii / y / w each written once, x read once
+            st = plan.op_streams(36, ops.F[plan.perm])
+            nload_f = int(((st["fwd"][0] != 0) | (st["fwd"][1] >= 0)).sum())
+            nload_b = int((st["bwd"][0] == 1).sum() * 2 + (st["bwd"][0] > 1).sum())
+            per_sample = 8 * (nload_f + nload_b + 2 * plan.nnzL + 4 * ops.n + pairs.xdim + pairs.n_obs)
+            alg = S * per_sample
             ach = alg / (ms[dom] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                    "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms[dom]}
 
         cpu = None
@@ -178,10 +194,22 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0},
+            "kernels_serial_ms": serial_ms,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/r01_pmc_summary.json); None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"].get(kernel)
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, phi, Xs, res, pairs):

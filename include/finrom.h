@@ -64,6 +64,9 @@ int finrom_stream_sync(void* stream);
  * stream; finrom_profile_read synchronises and returns, for kernel slot `slot`
  * (0 <= slot < finrom_profile_slots()), its name, launch count and total milliseconds. */
 int finrom_profile_enable(int on);
+/* finrom_solve_pairs runs its two halves on two streams (default, 1) or serialised on the caller's
+ * stream (0; stand-alone kernel timings).  Same results either way. */
+int finrom_set_overlap(int on);
 int finrom_profile_reset(void);
 int finrom_profile_slots(void);
 int finrom_profile_read(int slot, const char** name, int64_t* launches, double* total_ms);
