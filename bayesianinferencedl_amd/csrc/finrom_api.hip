@@ -189,13 +189,14 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
       if (t >= a->nops_fwd - 2 * VM_CHUNK && (k != 0 || B != a->cache_slots + 1)) return bad("forward stream tail (must be padding)");
     }
     std::fill(stored.begin(), stored.end(), -10);
+    auto need1 = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 1 <= c; };   // backward: fetched per chunk
     for (int t = 0; t < a->nops_bwd; ++t) {
       const int k = a->bwd_kind[t], A = a->bwd_a[t], B = a->bwd_b[t], D = a->bwd_d[t], c = t / VM_CHUNK;
       switch (k) {
         case 0: break;
-        case 1: if (!need(A, c) || !need(B, c)) return bad("backward WFMA op"); break;
-        case 3: if (!need(A, c)) return bad("backward WSET op"); break;
-        case 5: if (!need(A, c) || D < nnzL + n || D >= gsize) return bad("backward WFIN op"); stored[D] = c; break;
+        case 1: if (!need1(A, c) || !need1(B, c)) return bad("backward WFMA op"); break;
+        case 3: if (!need1(A, c)) return bad("backward WSET op"); break;
+        case 5: if (!need1(A, c) || D < nnzL + n || D >= gsize) return bad("backward WFIN op"); stored[D] = c; break;
         default: return bad("backward op kind");
       }
       if (t >= a->nops_bwd - 2 * VM_CHUNK && k != 0) return bad("backward stream tail (must be NOP padding)");
@@ -298,6 +299,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   RomDev& d = h->d;
   d.n = a->n; d.r = r; d.rp = rp; d.NB = NB; d.P = a->P; d.n_obs = a->n_obs;
   d.solve_in_lds = rp <= 176 ? 1 : 0;
+  d.clock_probe = getenv("FINROM_CLOCK_PROBE") != nullptr;
   d.n_phases = 0;
   std::vector<double> tv; std::vector<int> pidx;
   auto push_slot = [&](std::vector<double>& T, std::vector<int>& Pi, const std::vector<int>& rows4, int t) {
@@ -331,6 +333,35 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
     for (int t = 0; t < nt; ++t) push_slot(tv, pidx, rows4, t);
     nslots += nt;
   }
+  // chunk images for the LDS-staged kernel: whole k-steps of one phase, <= 32 KiB, padded to 1 KiB
+  std::vector<int> ch_nt, ch_nks, ch_off, ch_bytes;
+  std::vector<double> tvc;
+  d.n_chunks = 0;
+  if (NB <= 5) {
+    const size_t cap = 24 * 1024;   // = ROM_CHUNK_BYTES (rom_kernels.hip): 2 buffers + theta = 50 KiB per workgroup
+    for (int ph = 0; ph < d.n_phases; ++ph) {
+      const int nt = d.phase_nt[ph];
+      if (nt == 0) continue;
+      const size_t per_ks = (size_t)nt * 4 * rp * 8 + (size_t)nt * 4 * 4;
+      const int max_ks = std::max<int>(1, (int)(cap / per_ks));
+      if (per_ks > cap) { d.n_chunks = 0; ch_nt.clear(); break; }
+      for (int ks = d.phase_ks0[ph]; ks < d.phase_ks1[ph]; ks += max_ks) {
+        const int nks = std::min(max_ks, d.phase_ks1[ph] - ks);
+        const int slot = d.phase_slot0[ph] + (ks - d.phase_ks0[ph]) * nt;
+        const size_t nrows = (size_t)nks * nt * 4;
+        const size_t off = tvc.size();
+        tvc.insert(tvc.end(), tv.begin() + (size_t)slot * 4 * rp, tv.begin() + (size_t)slot * 4 * rp + nrows * rp);
+        const size_t nint = nrows;                      // theta indices, two per double
+        tvc.resize(tvc.size() + (nint + 1) / 2, 0.0);
+        std::memcpy(reinterpret_cast<char*>(tvc.data()) + (off + nrows * rp) * 8, &pidx[(size_t)slot * 4], nint * 4);
+        size_t bytes = (tvc.size() - off) * 8;
+        bytes = (bytes + 1023) / 1024 * 1024;
+        tvc.resize(off + bytes / 8, 0.0);
+        ch_nt.push_back(nt); ch_nks.push_back(nks); ch_off.push_back((int)off); ch_bytes.push_back((int)bytes);
+      }
+    }
+    d.n_chunks = (int)ch_nt.size();
+  }
   tv.resize(tv.size() + (size_t)4 * 4 * rp, 0.0);          // one k-step of padding for the prefetch
   pidx.resize(pidx.size() + 16, 0);
 
@@ -353,6 +384,13 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   if (rtv.empty()) { rtv.assign(4 * rp, 0.0); rpi.assign(4, 0); rf.assign(4, 0.0); }
 
   int rc = 0;
+  if (d.n_chunks > 0) {
+    if (!rc) rc = up(h->owned, &d.ch_nt, ch_nt.data(), ch_nt.size());
+    if (!rc) rc = up(h->owned, &d.ch_nks, ch_nks.data(), ch_nks.size());
+    if (!rc) rc = up(h->owned, &d.ch_off, ch_off.data(), ch_off.size());
+    if (!rc) rc = up(h->owned, &d.ch_bytes, ch_bytes.data(), ch_bytes.size());
+    if (!rc) rc = up(h->owned, &d.tvc, tvc.data(), tvc.size());
+  }
   if (!rc) rc = up(h->owned, &d.tv, tv.data(), tv.size());
   if (!rc) rc = up(h->owned, &d.pidx, pidx.data(), pidx.size());
   if (!rc) rc = up(h->owned, &d.rhs_tv, rtv.data(), rtv.size());
@@ -386,10 +424,14 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
     int rc;
     if ((rc = h->Ar.reserve((size_t)Sc * (d.rp * (d.rp + 1) / 2) * sizeof(double)))) return rc;
     if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
-    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, st))) return rc;
+    // A_r is factored inside the projection kernel (in registers, MFMA trailing updates) unless the caller
+    // wants A_r itself back (the state the reference's gradients use) or the basis needs more than one wave
+    const int factor = ((A_r == nullptr || getenv("FINROM_DEBUG_RETURN_FACTOR") != nullptr) && d.NB <= 6 &&
+                        getenv("FINROM_NO_FUSED_CHOL") == nullptr) ? 1 : 0;   // debug: A_r output then holds L
+    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, factor, info ? info + s0 : nullptr, st))) return rc;
     if ((rc = launch_rom_solve(d, (const double*)h->Ar.p, (const double*)h->Br.p, Sc, w_r ? w_r + s0 * d.r : nullptr,
                                qoi_r ? qoi_r + s0 * d.n_obs : nullptr, A_r ? A_r + s0 * (int64_t)d.r * d.r : nullptr,
-                               B_r ? B_r + s0 * d.r : nullptr, info ? info + s0 : nullptr, st))) return rc;
+                               B_r ? B_r + s0 * d.r : nullptr, info ? info + s0 : nullptr, factor, st))) return rc;
   }
   return 0;
 }
@@ -408,7 +450,9 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   if (S == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (!rom->side) {
-    FR_HIP(hipStreamCreateWithFlags(&rom->side, hipStreamNonBlocking));
+    int lo = 0, hi = 0;
+    FR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // numerically lower = higher priority
+    FR_HIP(hipStreamCreateWithPriority(&rom->side, hipStreamNonBlocking, hi));
     FR_HIP(hipEventCreateWithFlags(&rom->ev_fork, hipEventDisableTiming));
     FR_HIP(hipEventCreateWithFlags(&rom->ev_join, hipEventDisableTiming));
   }
@@ -424,9 +468,11 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     FR_HIP(hipEventRecord(rom->ev_fork, st));
     FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
   }
-  if ((rc = finrom_fom_solve(fom, x, S, qoi, w, info, st))) return rc;
+  // ROM half first, on a high-priority stream: its 4-wave, 160-VGPR workgroups need large contiguous
+  // register ranges, so they claim their slots before the small FOM waves fill the remaining ones
   if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, side))) return rc;
   if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return rc;
+  if ((rc = finrom_fom_solve(fom, x, S, qoi, w, info, st))) return rc;
   if (overlap) {
     FR_HIP(hipEventRecord(rom->ev_join, side));
     FR_HIP(hipStreamWaitEvent(st, rom->ev_join, 0));

@@ -77,9 +77,14 @@ constexpr int ROM_MAX_PHASES = 8;
 struct RomDev {
   int n, r, rp, NB, P, n_obs;           // rp = 16*NB padded basis size
   int solve_in_lds;                     // packed factor fits in LDS (rp <= 176)
+  int clock_probe;                      // FINROM_CLOCK_PROBE: a few workgroups print their shader clock (diagnostic)
   // psi tables, rows grouped 4 per k-step and sorted by term count into phases of constant NT
   int n_phases;
   int phase_nt[ROM_MAX_PHASES], phase_ks0[ROM_MAX_PHASES], phase_ks1[ROM_MAX_PHASES], phase_slot0[ROM_MAX_PHASES];
+  // the same tables cut into LDS-sized chunks of whole k-steps (LDS-staged kernel, NB <= 5)
+  int n_chunks;
+  const int* ch_nt; const int* ch_nks; const int* ch_off; const int* ch_bytes;   // [n_chunks]; ch_off in doubles
+  const double* tvc;                    // chunk images: values then theta indices, each padded to 1 KiB
   const double* tv;                     // [(nslots + 4) * 4 * rp]  padded r-vectors, slot-major
   const int* pidx;                      // [(nslots + 4) * 4]       theta index of each r-vector (0 = constant 1)
   // rows with a non-zero load F (root nodes), same slot format with a runtime term count
@@ -87,8 +92,8 @@ struct RomDev {
   const double* rhs_tv; const int* rhs_pidx; const double* rhs_f;
   const double* obs_phi;                // [n_obs x r]
 };
-int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, hipStream_t st);
+int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st);
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r,
-                     double* qoi_r, double* Ar_out, double* Br_out, int* info, hipStream_t st);
+                     double* qoi_r, double* Ar_out, double* Br_out, int* info, int factored, hipStream_t st);
 
 }  // namespace finrom

@@ -88,7 +88,7 @@ enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
 // prove that the stores to G never clobber them and fetch the descriptors with SCALAR loads
 // (s_load_dwordx16); through the by-value struct they become vector loads + v_readfirstlane whose
 // s_waitcnt vmcnt(0) drains the operand prefetch on every op.
-__global__ __launch_bounds__(64) void fom_vm_kernel(FomDev p, const int* __restrict__ fA, const int* __restrict__ fKB,
+__global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __restrict__ fA, const int* __restrict__ fKB,
                                                     const int* __restrict__ fD, const int* __restrict__ bA,
                                                     const int* __restrict__ bKB, const int* __restrict__ bD,
                                                     const double* __restrict__ rhs, const int* __restrict__ obs_ptr,
@@ -161,32 +161,28 @@ __global__ __launch_bounds__(64) void fom_vm_kernel(FomDev p, const int* __restr
   // ---- backward: L^T w = y, w overwrites y ----------------------------------------------
   if (p.debug_phases & 2) {
     const int* __restrict__ A = bA; const int* __restrict__ KB = bKB; const int* __restrict__ D = bD;
-    double a1[VM_CHUNK], b1[VM_CHUNK], a2[VM_CHUNK], b2[VM_CHUNK];
-#define VM_LOAD2(bufa, bufb, c)                                               \
-  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
-    const int a_ = A[(c) * VM_CHUNK + u];                                     \
-    const int b_ = (KB[(c) * VM_CHUNK + u] >> 8) - 1;                         \
-    bufa[u] = G[(int64_t)(a_ < 0 ? 0 : a_) * 64];                             \
-    bufb[u] = G[(int64_t)(b_ < 0 ? 0 : b_) * 64];                             \
-  }
-#define VM_EXEC_B(bufa, bufb, c)                                              \
-  int kbv[VM_CHUNK], dv[VM_CHUNK];                                            \
-  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = KB[(c) * VM_CHUNK + u]; dv[u] = D[(c) * VM_CHUNK + u]; } \
-  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
-    const int kind = kbv[u] & 255;                                            \
-    if (kind == B_WFMA) acc = fma(-bufa[u], bufb[u], acc);                    \
-    else if (kind == B_WSET) acc = bufa[u];                                   \
-    else if (kind == B_WFIN) G[(int64_t)dv[u] * 64] = acc * bufa[u];          \
-  }
-    VM_LOAD2(a1, b1, 0)
-    for (int c = 0; c < p.nchunks_bwd; c += 2) {
-      VM_LOAD2(a2, b2, c + 1)
-      { VM_EXEC_B(a1, b1, c) }
-      VM_LOAD2(a1, b1, c + 2)
-      { VM_EXEC_B(a2, b2, c + 1) }
+    // short stream (one op per entry of L): fetched chunk by chunk without double buffering, which keeps
+    // the kernel under 96 VGPRs so that two of its waves and two projection waves share a SIMD
+    double a1[VM_CHUNK], b1[VM_CHUNK];
+    for (int c = 0; c < p.nchunks_bwd; ++c) {
+      int kbv[VM_CHUNK], dv[VM_CHUNK];
+#pragma unroll
+      for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = KB[c * VM_CHUNK + u]; dv[u] = D[c * VM_CHUNK + u]; }
+#pragma unroll
+      for (int u = 0; u < VM_CHUNK; ++u) {
+        const int a_ = A[c * VM_CHUNK + u];
+        const int b_ = (kbv[u] >> 8) - 1;
+        a1[u] = G[(int64_t)(a_ < 0 ? 0 : a_) * 64];
+        b1[u] = G[(int64_t)(b_ < 0 ? 0 : b_) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < VM_CHUNK; ++u) {
+        const int kind = kbv[u] & 255;
+        if (kind == B_WFMA) acc = fma(-a1[u], b1[u], acc);
+        else if (kind == B_WSET) acc = a1[u];
+        else if (kind == B_WFIN) G[(int64_t)dv[u] * 64] = acc * a1[u];
+      }
     }
-#undef VM_EXEC_B
-#undef VM_LOAD2
   }
 #undef VM_LOAD1
 

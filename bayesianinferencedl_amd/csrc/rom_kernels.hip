@@ -19,20 +19,24 @@ namespace finrom {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // One k-step = 4 rows of psi.  Rows are sorted by their number of terms, so the k-steps form a
-// few PHASES with a compile-time term count NT: slot t of k-step ks is 4 padded r-vectors at
-//   tv[((slot0 + (ks - ks0) * NT + t) * 4 + q) * rp + col],   theta index pidx[(slot) * 4 + q],
+// few PHASES with a constant term count nt (<= 4): slot t of k-step ks is 4 padded r-vectors at
+//   tv[((slot0 + (ks - ks0) * nt + t) * 4 + q) * rp + col],   theta index pidx[(slot) * 4 + q],
 // i.e. every address is a function of the loop counter (no dependent index loads), and the raw
 // table values of k-step ks+1 are fetched into registers while the MFMAs of k-step ks issue.
-template <int NB, int NT>
-__device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const int* __restrict__ pidx, int slot, int rp,
-                                           int q, int c, double (&raw)[NT][NB], int (&pi)[NT]) {
+constexpr int ROM_MAX_NT = 4;
+
+template <int NB>
+__device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const int* __restrict__ pidx, int slot, int nt,
+                                           int rp, int q, int c, double (&raw)[ROM_MAX_NT][NB], int (&pi)[ROM_MAX_NT]) {
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int row = (slot + t) * 4 + q;
-    pi[t] = pidx[row];
-    const double* src = tv + (int64_t)row * rp + c;
+  for (int t = 0; t < ROM_MAX_NT; ++t) {
+    if (t < nt) {                                  // wave-uniform
+      const int row = (slot + t) * 4 + q;
+      pi[t] = pidx[row];
+      const double* src = tv + (int64_t)row * rp + c;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) raw[t][b] = src[16 * b];
+      for (int b = 0; b < NB; ++b) raw[t][b] = src[16 * b];
+    }
   }
 }
 
@@ -46,14 +50,15 @@ __device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB 
   // Bases wider than 128 spill accumulators; spill code next to inline asm is not hazard-safe
   // (the compiler cannot see that the asm is an MFMA), so those sizes use the compiler-managed builtin.
   constexpr bool kAsm = NB <= 8;
-  if constexpr (kAsm) asm volatile("s_nop 7" ::: "memory");
   int idx = 0, mine = 0;
 #pragma unroll
   for (int ti = 0; ti < NB; ++ti)
 #pragma unroll
     for (int tj = ti; tj < NB; ++tj) {
       if (idx % NW == W) {
-        if constexpr (kAsm) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[mine]) : "v"(v[ti]), "v"(v[tj]));
+        // the wait states for "VALU wrote an operand -> MFMA reads it" sit INSIDE the asm statement: a
+        // separate s_nop statement can be scheduled away from the MFMA it is meant to protect
+        if constexpr (kAsm) asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[mine]) : "v"(v[ti]), "v"(v[tj]));
         else acc[mine] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[mine], 0, 0, 0);
         ++mine;
       }
@@ -61,53 +66,145 @@ __device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB 
     }
 }
 
-template <int NB, int NW, int W, int NT>
-__device__ __forceinline__ void run_phase(const RomDev& p, int ph, const double* thw, int q, int c,
-                                          d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
-  const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph];
-  if (ks0 >= ks1) return;
-  double raw[NT][NB];
-  int pi[NT];
-  load_kstep<NB, NT>(p.tv, p.pidx, slot0, p.rp, q, c, raw, pi);
-#pragma unroll 1
-  for (int ks = ks0; ks < ks1; ++ks) {
-    double v[NB];
+// Wait for the in-flight inline-asm MFMAs before the compiler-scheduled code reads their results: the
+// wait carries every accumulator as an in/out operand, so no reader can be scheduled above it.
+template <int N>
+__device__ __forceinline__ void mfma_drain(d4 (&acc)[N]) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) v[b] = 0.0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const double thp = thw[pi[t]];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) v[b] = fma(thp, raw[t][b], v[b]);
-    }
-    // raw is dead now: fetch k-step ks+1 into it; the loads fly while this k-step's MFMAs issue
-    // (the table is padded by one k-step of zeros, so the last prefetch stays inside it)
-    load_kstep<NB, NT>(p.tv, p.pidx, slot0 + (ks + 1 - ks0) * NT, p.rp, q, c, raw, pi);
-    mfma_tiles<NB, NW, W>(v, acc);
+  for (int t = 0; t < N; ++t) {
+    if (t == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[t]));
+    else asm volatile("" : "+v"(acc[t]));
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// In-register blocked Cholesky A_r = U^T U on the MFMA accumulator tiles (one wave, NW == 1).
+// Tile (ti <= tj) holds rows 16ti.., columns 16tj.. in the C/D layout (lane: q = row&3 group, c = column;
+// register g: row q + 4g).  Block row kb: 16 right-looking steps (pivot, scale, rank-1 update) with lane
+// shuffles inside the block row; the update of the trailing tiles is 4 MFMAs per tile whose operands ARE
+// the freshly computed registers of U (A[i][k] = U[k][i] lives exactly where the C/D layout put it).
+// ---------------------------------------------------------------------------------------
+template <int NB>
+__device__ __forceinline__ int tile_index(int ti, int tj) { return ti * NB - (ti * (ti - 1)) / 2 + (tj - ti); }
+
+template <int NB>
+__device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, int c, int r) {
+  int bad = 0;
+  // padding rows/columns (>= r) of psi^T psi are zero: give them a unit diagonal
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (q + 4 * g == c && 16 * t + c >= r) acc[tile_index<NB>(t, t)][g] = 1.0;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    const int dg = tile_index<NB>(kb, kb);
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int qs = st & 3, gs = st >> 2;
+      const double piv = __shfl(acc[dg][gs], qs * 16 + st);
+      bad |= !(piv > 0.0);
+      double rinv = __builtin_amdgcn_rsq(piv);                 // 1/sqrt: hardware estimate + Newton steps
+#pragma unroll
+      for (int it = 0; it < 4; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+      const double sc = (q == qs) ? rinv : 1.0;
+#pragma unroll
+      for (int tj = kb; tj < NB; ++tj) acc[dg + (tj - kb)][gs] *= sc;     // row st of U is final
+      double m[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double v = __shfl(acc[dg][gs], qs * 16 + ((q + 4 * g) & 15));
+        m[g] = (q + 4 * g > st) ? v : 0.0;                                // only rows below the pivot row
+      }
+#pragma unroll
+      for (int tj = kb; tj < NB; ++tj) {
+        const double rv = __shfl(acc[dg + (tj - kb)][gs], qs * 16 + c);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[dg + (tj - kb)][g] = fma(-m[g], rv, acc[dg + (tj - kb)][g]);
+      }
+    }
+    // trailing update: T(ti,tj) -= U(kb,ti)^T U(kb,tj)
+    if (kb + 1 < NB) {
+      // operands are copied out of the accumulator tuples into plain 64-bit registers first (a sub-register
+      // of a 256-bit inline-asm tuple is not guaranteed to be a legal, even-aligned MFMA source)
+      double neg[NB][4], pos[NB][4];
+#pragma unroll
+      for (int ti = kb + 1; ti < NB; ++ti)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { pos[ti][g] = acc[dg + (ti - kb)][g]; neg[ti][g] = -pos[ti][g]; }
+      // k-step g outermost: consecutive MFMAs hit different tiles; the drain between k-steps covers the
+      // MFMA -> same-accumulator MFMA hazard that hipcc cannot pad around inline asm
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int ti = kb + 1; ti < NB; ++ti)
+#pragma unroll
+          for (int tj = ti; tj < NB; ++tj)
+            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0"
+                         : "+v"(acc[tile_index<NB>(ti, tj)]) : "v"(neg[ti][g]), "v"(pos[tj][g]));
+        mfma_drain(acc);
+      }
+    }
+  }
+  return bad;
 }
 
 template <int NB, int NW, int W>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
-                                              double* __restrict__ Ar, double* __restrict__ Br) {
+                                              double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                              int* __restrict__ info) {
   constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
   const int q = lane >> 4, c = lane & 15;
   d4 acc[NTL];
 #pragma unroll
   for (int t = 0; t < NTL; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 
-  for (int ph = 0; ph < p.n_phases; ++ph) {
-    switch (p.phase_nt[ph]) {
-      case 1: run_phase<NB, NW, W, 1>(p, ph, thw, q, c, acc); break;
-      case 2: run_phase<NB, NW, W, 2>(p, ph, thw, q, c, acc); break;
-      case 3: run_phase<NB, NW, W, 3>(p, ph, thw, q, c, acc); break;
-      case 4: run_phase<NB, NW, W, 4>(p, ph, thw, q, c, acc); break;
-      default: break;   // rom_create splits rows so that no phase has more than 4 terms
+  // ONE copy of the MFMA group for all phases (runtime term count): several unrolled copies make hipcc
+  // spill the inline-asm accumulators around every copy
+  {
+    double raw[ROM_MAX_NT][NB];
+    int pi[ROM_MAX_NT];
+    int ph = 0;
+    while (ph < p.n_phases && p.phase_ks0[ph] >= p.phase_ks1[ph]) ++ph;
+    if (ph < p.n_phases) load_kstep<NB>(p.tv, p.pidx, p.phase_slot0[ph], p.phase_nt[ph], p.rp, q, c, raw, pi);
+#pragma unroll 1
+    for (; ph < p.n_phases; ++ph) {
+      const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph], nt = p.phase_nt[ph];
+      // what follows the last k-step of this phase: the first k-step of the next non-empty phase (or padding)
+      int nph = ph + 1;
+      while (nph < p.n_phases && p.phase_ks0[nph] >= p.phase_ks1[nph]) ++nph;
+      const int next_slot = nph < p.n_phases ? p.phase_slot0[nph] : slot0 + (ks1 - ks0) * nt;
+      const int next_nt = nph < p.n_phases ? p.phase_nt[nph] : 1;
+#pragma unroll 1
+      for (int ks = ks0; ks < ks1; ++ks) {
+        double v[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) v[b] = 0.0;
+#pragma unroll
+        for (int t = 0; t < ROM_MAX_NT; ++t) {
+          if (t < nt) {
+            const double thp = thw[pi[t]];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) v[b] = fma(thp, raw[t][b], v[b]);
+          }
+        }
+        // raw is dead now: fetch the next k-step into it; the loads fly while this k-step's MFMAs issue
+        // (the table is padded by one k-step of zeros, so the last prefetch stays inside it)
+        const bool last = ks + 1 == ks1;
+        load_kstep<NB>(p.tv, p.pidx, last ? next_slot : slot0 + (ks + 1 - ks0) * nt, last ? next_nt : nt, p.rp, q, c, raw, pi);
+        mfma_tiles<NB, NW, W>(v, acc);
+      }
     }
   }
 
   // let the last MFMAs retire before their results are read (no hazard padding around inline asm)
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  if constexpr (NB <= 8) mfma_drain(acc);
+  if constexpr (NW == 1 && NB <= 6) {
+    if (factor) {      // A_r = U^T U in registers; what is written below is then U^T (= L, packed by columns)
+      const int bad = chol_tiles<NB>(acc, q, c, p.r);
+      if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
+    }
+  }
   // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15].
   // A_r is symmetric: tile (ti <= tj) element (row, col) is written as the LOWER element
   // (i = col, k = row) of the packed column-major lower triangle the solve kernel reads.
@@ -164,7 +261,8 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 // workgroup is 4 waves = 4/NW samples.
 template <int NB, int NW>
 __global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
-                                                       double* __restrict__ Ar, double* __restrict__ Br) {
+                                                       double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                                       int* __restrict__ info) {
   __shared__ double th[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t s = (int64_t)blockIdx.x * (4 / NW) + wave / NW;
@@ -175,27 +273,188 @@ __global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev
   __builtin_amdgcn_wave_barrier();
   const double* thw = th[wave];
   if constexpr (NW == 1) {
-    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br);
+    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info);
   } else if constexpr (NW == 2) {
-    if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br);
-    else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br);
+    if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br, factor, info);
+    else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br, factor, info);
   } else {
     switch (wave % 4) {
-      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br); break;
-      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br); break;
-      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br); break;
-      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br); break;
+      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info); break;
+      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info); break;
     }
   }
 }
 
-int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, hipStream_t st) {
+// ---------------------------------------------------------------------------------------
+// LDS-staged projection (bases up to r = 96, one wave per sample, 8 samples per workgroup).
+// The Psi tables are cut into chunks of whole k-steps (<= 24 KiB, constant term count); a chunk is
+// copied global -> LDS ONCE per workgroup with global_load_lds_dwordx4 (no VGPR round trip) while the
+// previous chunk is being consumed, so the 8 waves share one table fetch and the fetch has a whole
+// chunk of MFMA time (>10 us) to land -- which keeps this kernel MFMA-bound even while the FOM kernel
+// saturates the CU's vector-memory pipeline on the other stream.
+// LDS image of a chunk = its global bytes: [nks*NT*4 rows][rp] doubles, then nks*NT*4 theta indices.
+// With rp = 80 the 4 row-groups of a ds_read_b64 wave access fall on disjoint banks (640 B row pitch).
+// ---------------------------------------------------------------------------------------
+constexpr int ROM_CHUNK_BYTES = 24 * 1024;
+
+template <int NB>
+__device__ __forceinline__ void lds_chunk_compute(const double* __restrict__ buf, int nks, int nt, int rp, const double* thw,
+                                                  int q, int c, d4 (&acc)[NB * (NB + 1) / 2]) {
+  // ONE copy of the MFMA group (runtime term count): several unrolled copies make hipcc spill the
+  // inline-asm accumulators around every copy
+  const int* pidx = reinterpret_cast<const int*>(buf + (size_t)nks * nt * 4 * rp);
+  const int nrow = nks * nt;
+  double v[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) v[b] = 0.0;
+  int t = 0;
+#pragma unroll 1
+  for (int rowi = 0; rowi < nrow; ++rowi) {
+    const int row = rowi * 4 + q;
+    const double thp = thw[pidx[row]];
+    const double* src = buf + (size_t)row * rp + c;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v[b] = fma(thp, src[16 * b], v[b]);
+    if (++t == nt) {               // the slab of this k-step is complete
+      mfma_tiles<NB, 1, 0>(v, acc);
+      t = 0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v[b] = 0.0;
+    }
+  }
+}
+
+template <int NB, int WPB>      // WPB waves (= samples) per workgroup share each staged chunk
+__global__ __launch_bounds__(64 * WPB, (WPB == 8 ? 2 : 1)) void rom_proj_lds_kernel(RomDev p, const int* __restrict__ ch_nt,
+                                                              const int* __restrict__ ch_nks,
+                                                              const int* __restrict__ ch_off,
+                                                              const int* __restrict__ ch_bytes,
+                                                              const double* __restrict__ tvc,
+                                                              const double* __restrict__ theta, int64_t S,
+                                                              double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                                              int* __restrict__ info) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];     // [2][ROM_CHUNK_BYTES] + th[8][32]
+  double* th = reinterpret_cast<double*>(smem + 2 * ROM_CHUNK_BYTES);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t s = (int64_t)blockIdx.x * WPB + wave;
+  const bool live = s < S;
+  const long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_setprio(3);
+  double* thw = th + wave * 32;
+  if (lane == 0) thw[0] = 1.0;
+  if (live && lane < p.P) thw[lane + 1] = theta[s * p.P + lane];
+  const int q = lane >> 4, c = lane & 15;
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+
+  auto stage = [&](int g, int slot) {     // async copy of chunk g into LDS buffer `slot`, 1 KiB per wave-instruction
+    const char* src = reinterpret_cast<const char*>(tvc) + (size_t)ch_off[g] * 8;
+    char* dst = smem + slot * ROM_CHUNK_BYTES;
+    const int nb = ch_bytes[g];
+    for (int off = wave * 1024; off < nb; off += WPB * 1024)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int g = 0; g < p.n_chunks; ++g) {
+    if (g + 1 < p.n_chunks) stage(g + 1, (g + 1) & 1);
+    const double* buf = reinterpret_cast<const double*>(smem + (g & 1) * ROM_CHUNK_BYTES);
+    const int nks = ch_nks[g];
+    lds_chunk_compute<NB>(buf, nks, ch_nt[g], p.rp, thw, q, c, acc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk g+1 has landed (this wave's share)
+    __syncthreads();                                    // ... and everybody is done reading chunk g
+  }
+  if (!live) return;
+  if (p.clock_probe && threadIdx.x == 0 && (blockIdx.x % 2500) == 7) {
+    const long long dt = __builtin_amdgcn_s_memtime() - probe_t0, dr = __builtin_amdgcn_s_memrealtime() - probe_r0;
+    printf("[proj probe] block %d: %lld shader ticks, %lld x10ns -> clock %.0f MHz, main loop %.1f us\n", (int)blockIdx.x, dt, dr,
+           (double)dt / (double)dr * 100.0, dr * 0.01);
+  }
+
+  mfma_drain(acc);
+  if (factor) {
+    const int bad = chol_tiles<NB>(acc, q, c, p.r);
+    if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
+  }
+  const int R = p.rp;
+  double* A = Ar + s * (int64_t)(R * (R + 1) / 2);
+  int idx = 0;
+#pragma unroll
+  for (int ti = 0; ti < NB; ++ti)
+#pragma unroll
+    for (int tj = ti; tj < NB; ++tj) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * ti + q + 4 * g, col = 16 * tj + c;
+        if (ti != tj || col >= row) A[row * R - (row * (row - 1)) / 2 + col - row] = acc[idx][g];
+      }
+      ++idx;
+    }
+  // B_r = psi^T F over the root rows (rebuilt from the global table: a handful of k-steps, VALU only)
+  double bacc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
+  for (int ks = 0; ks < p.rhs_nk; ++ks) {
+    double v[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) v[b] = 0.0;
+    for (int t = 0; t < p.rhs_nt; ++t) {
+      const int row = (ks * p.rhs_nt + t) * 4 + q;
+      const double thp = thw[p.rhs_pidx[row]];
+      const double* src = p.rhs_tv + (int64_t)row * p.rp + c;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v[b] = fma(thp, src[16 * b], v[b]);
+    }
+    const double fk = p.rhs_f[ks * 4 + q];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bacc[b] = fma(v[b], fk, bacc[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    double x = bacc[b];
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    if (q == 0) Br[s * p.rp + 16 * b + c] = x;
+  }
+}
+
+template <int NB>
+static int launch_proj_lds(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                           hipStream_t st) {
+  constexpr int WPB = 4;
+  const size_t lds = 2 * ROM_CHUNK_BYTES + 8 * 32 * sizeof(double);
+  hipLaunchKernelGGL((rom_proj_lds_kernel<NB, WPB>), dim3((unsigned)((S + WPB - 1) / WPB)), dim3(64 * WPB), lds, st, p, p.ch_nt, p.ch_nks,
+                     p.ch_off, p.ch_bytes, p.tvc, theta, S, Ar, Br, factor, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                    hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_PROJ, st);
+  // The LDS-staged variant shares each table fetch among the 4 waves of a workgroup; measured on MI355X it
+  // is 8 % slower stand-alone (barriers) and no faster beside the FOM kernel, so it is opt-in.
+  if (p.n_chunks > 0 && getenv("FINROM_PROJ_LDS") != nullptr) {
+    switch (p.NB) {
+      case 1: return launch_proj_lds<1>(p, theta, S, Ar, Br, factor, info, st);
+      case 2: return launch_proj_lds<2>(p, theta, S, Ar, Br, factor, info, st);
+      case 3: return launch_proj_lds<3>(p, theta, S, Ar, Br, factor, info, st);
+      case 4: return launch_proj_lds<4>(p, theta, S, Ar, Br, factor, info, st);
+      case 5: return launch_proj_lds<5>(p, theta, S, Ar, Br, factor, info, st);
+      default: break;
+    }
+  }
   dim3 block(256);
 #define FR_CASE(N, W)                                                                              \
   case N: hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + (4 / W) - 1) / (4 / W))), \
-                             block, 0, st, p, theta, S, Ar, Br); break;
+                             block, 0, st, p, theta, S, Ar, Br, factor, info); break;
   switch (p.NB) {
     FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(5, 1) FR_CASE(6, 1)
     FR_CASE(7, 2) FR_CASE(8, 2) FR_CASE(9, 2)
@@ -220,7 +479,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int col_start(int k, int R) { return k * R - (k * (k - 1)) / 2; }
 
-template <bool IN_LDS, int NSET>
+template <bool IN_LDS, int NSET, bool FACTORED>
 __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* __restrict__ Arp,
                                                        const double* __restrict__ Br, int64_t S,
                                                        double* __restrict__ w_r, double* __restrict__ qoi_r,
@@ -254,7 +513,8 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
     for (; t < nv; t += 64) dst[t] = src[t];
   }
   __syncthreads();
-  for (int i = r + lane; i < R; i += 64) Lm[col_start(i, R)] = 1.0;
+  if constexpr (!FACTORED)
+    for (int i = r + lane; i < R; i += 64) Lm[col_start(i, R)] = 1.0;
   int row[NSET];
   bool ok[NSET];
   double b[NSET];
@@ -287,6 +547,10 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
   };
 
   int bad = 0;
+  if constexpr (FACTORED) {      // the projection kernel already factored A_r: Lm holds L = U^T
+    for (int i = lane; i < R; i += 64) invd[i] = 1.0 / Lm[col_start(i, R)];
+    __syncthreads();
+  } else
   for (int j0 = 0; j0 < R; j0 += 4) {
     double a[4][NSET];
 #pragma unroll
@@ -368,32 +632,36 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
   if (info != nullptr && lane == 0 && bad) atomicOr(&info[s], 2);
 }
 
-template <bool IN_LDS, int NSET>
+template <bool IN_LDS, int NSET, bool FACTORED>
 static int launch_solve_t(const RomDev& p, size_t lds, const double* Ar, const double* Br, int64_t S, double* w_r,
                           double* qoi_r, double* Ar_out, double* Br_out, int* info, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET, FACTORED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
     attr_set = true;
   }
-  hipLaunchKernelGGL((rom_solve_kernel<IN_LDS, NSET>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
+  hipLaunchKernelGGL((rom_solve_kernel<IN_LDS, NSET, FACTORED>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
   FR_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
-                     double* Ar_out, double* Br_out, int* info, hipStream_t st) {
+                     double* Ar_out, double* Br_out, int* info, int factored, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
   const size_t lds = ((p.solve_in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 2 * (size_t)p.rp) * sizeof(double);
   const int nset = (p.rp + 63) / 64;
-#define FR_SOLVE(L, N) return launch_solve_t<L, N>(p, lds, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info, st)
-  if (p.solve_in_lds) {
-    if (nset == 1) FR_SOLVE(true, 1);
-    if (nset == 2) FR_SOLVE(true, 2);
-    FR_SOLVE(true, 3);
+#define FR_SOLVE(L, N, F) return launch_solve_t<L, N, F>(p, lds, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info, st)
+  if (factored) {                       // only offered for rp <= 96 (one-wave projection)
+    if (nset == 1) FR_SOLVE(true, 1, true);
+    FR_SOLVE(true, 2, true);
   }
-  FR_SOLVE(false, 4);
+  if (p.solve_in_lds) {
+    if (nset == 1) FR_SOLVE(true, 1, false);
+    if (nset == 2) FR_SOLVE(true, 2, false);
+    FR_SOLVE(true, 3, false);
+  }
+  FR_SOLVE(false, 4, false);
 #undef FR_SOLVE
 }
 

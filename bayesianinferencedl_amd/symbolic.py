@@ -252,7 +252,7 @@ class CholeskyPlan:
 # The factorisation / substitution schedule is flattened into a stream of fixed-size ops that a
 # wave executes for its 64 samples.  The wave fetches the ops' global operands one CHUNK (16 ops)
 # ahead of executing them, so a value stored while chunk c executes may be fetched no earlier than
-# for chunk c+2.  This module orders the rows (any topological order of the elimination tree is a
+# for chunk c+2 (forward stream; the short backward stream is fetched chunk by chunk: c+1).  This module orders the rows (any topological order of the elimination tree is a
 # valid elimination order) and pads with NOPs so that rule always holds; tests/test_host_and_abi.py
 # replays the stream with exactly that prefetch semantics.
 #
@@ -267,8 +267,9 @@ OPB_NOP, OPB_WFMA, OPB_WSET, OPB_WFIN = 0, 1, 3, 5
 
 
 class _Emitter:
-    def __init__(self, nvals, pad_b=-1):
+    def __init__(self, nvals, pad_b=-1, distance=2):
         self.pad_b = pad_b                                   # b field of padding ops (forward: the ZERO slot)
+        self.distance = distance                             # chunks between a store and the first fetch of the value
         self.kind, self.a, self.b, self.d = [], [], [], []
         self.store_chunk = np.full(nvals, -10, np.int64)     # chunk in which a value was last stored
 
@@ -278,7 +279,7 @@ class _Emitter:
     def emit(self, kind, a=-1, b=-1, d=-1, loads=(), stores=()):
         need = 0
         for g in loads:
-            need = max(need, (self.store_chunk[g] + 2) * CHUNK)
+            need = max(need, (self.store_chunk[g] + self.distance) * CHUNK)
         while self.pos() < need:
             self.kind.append(0); self.a.append(-1); self.b.append(self.pad_b); self.d.append(-1)
         c = self.pos() // CHUNK
@@ -377,7 +378,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
 
     # ---------------- backward: L^T w = y (w overwrites y) --------------------------------
     col_ptr = plan.col_ptr.astype(np.int64)
-    emb = _Emitter(nnzL + 2 * n)
+    emb = _Emitter(nnzL + 2 * n, distance=1)     # the backward interpreter fetches chunk c right before executing it
     ndeps_b = np.diff(col_ptr)
     users_b = [[] for _ in range(n)]
     for i in range(n):
@@ -401,7 +402,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
             heapq.heappush(eligible, (nh, i))
         if eligible:
             _, i = heapq.heappop(eligible)
-            ready = max([done_b[plan.col_row[c]] + 2 for c in range(col_ptr[i], col_ptr[i + 1])], default=0)
+            ready = max([done_b[plan.col_row[c]] + 1 for c in range(col_ptr[i], col_ptr[i + 1])], default=0)
             if ready > cur and (eligible or (waiting and waiting[0][0] < ready)):
                 heapq.heappush(waiting, (ready, -depth[i], i))
                 continue
@@ -448,7 +449,10 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
             return va, vb
         nxt = fetch(0)
         for c in range(nch):
-            cur, nxt = nxt, fetch(c + 1)            # chunk c+1 is fetched BEFORE chunk c executes
+            if backward:
+                cur = fetch(c)                      # backward: chunk c is fetched right before it executes
+            else:
+                cur, nxt = nxt, fetch(c + 1)        # forward: chunk c+1 is fetched BEFORE chunk c executes
             for u in range(CHUNK):
                 t = c * CHUNK + u
                 k, ld = kind[t], cur[0][u]

@@ -80,6 +80,13 @@ def test_rom_parity(problems, spaces, m, r):
     assert rel(res["qoi_r"][:n_check], WR @ ro.B_obs_phi.T) < TOL
     assert rel(res["w_r"][:n_check] @ phi.T, WR @ phi.T) < TOL
     assert rel(res["w_r"][:n_check], WR) < 1e-8          # orthonormal basis; cond(A_r) ~ 1e7
+    # without the A_r/B_r outputs the reduced matrix is factored inside the projection kernel
+    # (in-register blocked Cholesky, r <= 96): a different code path, same contract
+    fused = rom.forward_nine_param_reduced_batch(TH)
+    assert (fused["info"] == 0).all()
+    assert rel(fused["qoi_r"][:n_check], WR @ ro.B_obs_phi.T) < TOL
+    assert rel(fused["w_r"][:n_check] @ phi.T, WR @ phi.T) < TOL
+    assert rel(fused["w_r"], res["w_r"]) < 1e-8
 
 
 def test_pairs_field_parity(problems, spaces):
