@@ -179,7 +179,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
       const int k = a->fwd_kind[t], A = a->fwd_a[t], B = a->fwd_b[t], D = a->fwd_d[t], c = t / VM_CHUNK;
       switch (k) {
         case 0: if ((A >= 0 && !need(A, c)) || A < -1 || B < 0 || B >= a->cache_slots + 2) return bad("forward FMA op"); break;
-        case 2: if (!need(A, c) || !need(D, c)) return bad("forward FMAG op"); break;
+        case 3: case 4: if (!need(A, c)) return bad("forward LDX/FMAX op"); break;
         case 5: if (!need(A, c) || D < 0 || D >= nnzL || B < -1 || B >= a->cache_slots) return bad("forward FINOFF op"); stored[D] = c; break;
         case 6: if (D < 0 || D >= nnzL || B < 0 || B >= n) return bad("forward FINDIAG op"); stored[D] = c; stored[nnzL + B] = c; break;
         case 7: if (D < 0 || D >= n) return bad("forward YSET op"); break;

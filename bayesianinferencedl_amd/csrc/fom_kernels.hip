@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void fom_assemble_kernel(FomDev p, const int* 
 // Global operands of chunk c+1 are in flight while chunk c executes (double-buffered in
 // registers); the op descriptors themselves are sequential scalar loads.
 // ---------------------------------------------------------------------------------------
-enum { F_FMA = 0, F_FMAG = 2, F_FINOFF = 5, F_FINDIAG = 6, F_YSET = 7, F_FINY = 8 };
+enum { F_FMA = 0, F_LDX = 3, F_FMAX = 4, F_FINOFF = 5, F_FINDIAG = 6, F_YSET = 7, F_FINY = 8 };
 enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
 
 // The op arrays are separate __restrict__ kernel parameters on purpose: only then can the compiler
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   rc[p.cache_slots * 64] = -1.0;          // NEG1 slot: "acc = A_e" is an FMA against it
   rc[(p.cache_slots + 1) * 64] = 0.0;     // ZERO slot: padding ops
   int bad = 0;
-  double acc = 0.0, inv = 0.0;
+  double acc = 0.0, inv = 0.0, xreg = 0.0;
 
+  // (padding ops, a < 0, re-read element 0: a uniform branch per load to skip them measured slower)
 #define VM_LOAD1(buf, c)                                                      \
   _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
     const int a_ = A[(c) * VM_CHUNK + u];                                     \
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
     } else {                                                                  \
       const int d = dv[u];                                                    \
       switch (kind) {                                                         \
-        case F_FMAG: acc = fma(-G[(int64_t)d * 64], ld, acc); break;          \
+        case F_LDX: xreg = ld; break;             /* row entry beyond the LDS cache */ \
+        case F_FMAX: acc = fma(-xreg, ld, acc); break;                        \
         case F_FINOFF: {                                                      \
           const double l = acc * ld;                                          \
           G[(int64_t)d * 64] = l;                                             \

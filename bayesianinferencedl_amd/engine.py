@@ -13,7 +13,7 @@ from . import _ffi
 from ._ffi import DeviceBuffer, FomDesc, RomDesc, check, f64, i32, lib
 
 
-ROW_CACHE_SLOTS = 36     # LDS row cache of the FOM interpreter: 18 KiB per wave, 7 waves per CU
+ROW_CACHE_SLOTS = 42     # LDS row cache of the FOM interpreter: (42+2) x 512 B = 22 KiB per wave, 7 waves per CU (154 KiB)
 
 
 def _is_torch(x):

@@ -262,7 +262,8 @@ CHUNK = 16
 # forward kinds.  Kind 0 is the only common one and is branch-free on the device:
 #   acc -= rc[b] * G[a]        with two constant LDS slots after the row cache: NEG1 (-1.0) and ZERO (0.0),
 # so "acc = A_e" is an FMA against NEG1 (every FIN* op leaves acc = 0) and padding is an FMA against ZERO.
-OP_FMA, OP_FMAG, OP_FINOFF, OP_FINDIAG, OP_YSET, OP_FINY = 0, 2, 5, 6, 7, 8
+OP_FMA, OP_LDX, OP_FMAX, OP_FINOFF, OP_FINDIAG, OP_YSET, OP_FINY = 0, 3, 4, 5, 6, 7, 8
+# a row entry beyond the LDS row cache is fetched like any other operand: LDX x = G[a]; FMAX acc -= x * G[a]
 OPB_NOP, OPB_WFMA, OPB_WSET, OPB_WFIN = 0, 1, 3, 5
 
 
@@ -352,7 +353,8 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
                 if slot < cache_slots:
                     em.emit(OP_FMA, a=pb, b=slot, loads=(pb,))
                 else:
-                    em.emit(OP_FMAG, a=pb, d=pa, loads=(pb, pa))
+                    em.emit(OP_LDX, a=pa, loads=(pa,))
+                    em.emit(OP_FMAX, a=pb, loads=(pb,))
             if e == e1 - 1:
                 em.emit(OP_FINDIAG, b=i, d=e, stores=(e, IV + i))
             else:
@@ -366,7 +368,8 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
             if slot < cache_slots:
                 em.emit(OP_FMA, a=yk, b=slot, loads=(yk,))
             else:
-                em.emit(OP_FMAG, a=yk, d=e, loads=(yk, e))
+                em.emit(OP_LDX, a=e, loads=(e,))
+                em.emit(OP_FMAX, a=yk, loads=(yk,))
         em.emit(OP_FINY, d=YV + i, stores=(YV + i,))
         done_chunk[i] = (em.pos() - 1) // CHUNK
         for u in users[i]:
@@ -439,6 +442,7 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
         nch = len(kind) // CHUNK
         acc = 0.0
         inv = 0.0
+        xreg = 0.0
 
         def fetch(c):
             if c >= nch:
@@ -462,7 +466,8 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
                     elif k == OPB_WFIN: G[d[t]] = acc * ld
                 else:
                     if k == OP_FMA: acc -= rc[b[t]] * ld
-                    elif k == OP_FMAG: acc -= G[d[t]] * ld
+                    elif k == OP_LDX: xreg = ld
+                    elif k == OP_FMAX: acc -= xreg * ld
                     elif k == OP_FINOFF:
                         l = acc * ld; G[d[t]] = l; acc = 0.0
                         if b[t] >= 0: rc[b[t]] = l

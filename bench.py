@@ -157,7 +157,7 @@ def main():
         cand = {k: v[1] for k, v in prof.items()}
         dom = max(cand, key=cand.get) if any(cand.values()) else "rom_proj_mfma"
         roof = None
-        traffic = measured_traffic(dom)
+        traffic = measured_traffic(dom, f"{args.params}/m{args.m}/r{args.r}/S{S}")
         if dom == "rom_proj_mfma" and ms[dom] > 0:
             alg = S * (fl["syrk_sym"] + 2 * solver_r._rom.nterms * args.r + fl["rhs"])
             ach = alg / (ms[dom] * 1e-3) / 1e12
@@ -167,7 +167,7 @@ def main():
         elif ms.get(dom, 0) > 0:
             # FOM interpreter: per sample one 8-B operand per multiply-add of the schedule
             # (the other operand sits in LDS), L / 1/L_ii / y / w each written once, x read once
-            st = plan.op_streams(36, ops.F[plan.perm])
+            st = plan.op_streams(42, ops.F[plan.perm])
             nload_f = int(((st["fwd"][0] != 0) | (st["fwd"][1] >= 0)).sum())
             nload_b = int((st["bwd"][0] == 1).sum() * 2 + (st["bwd"][0] > 1).sum())
             per_sample = 8 * (nload_f + nload_b + 2 * plan.nnzL + 4 * ops.n + pairs.xdim + pairs.n_obs)
@@ -201,13 +201,17 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of this same command
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/r01_pmc_summary.json); None if absent."""
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/r01_pmc_summary.json); None if the
+    summary is absent or was taken on another workload."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"].get(kernel)
+            d = json.load(f)
+        if d.get("workload_key") != workload_key:
+            return None
+        return d["hbm_bytes_per_launch"].get(kernel)
     except Exception:
         return None
 

@@ -92,7 +92,7 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
  * rc = the LDS cache of the row being eliminated (cache_slots entries):
  *   forward  0 FMA acc -= rc[b]*G[a]   (rc[cache_slots] == -1 and rc[cache_slots+1] == 0 are constants:
  *                  "acc = A_e" is an FMA against the first, padding an FMA against the second with a = -1)
- *            2 FMAG acc -= G[d]*G[a]
+ *            3 LDX x = G[a] | 4 FMAX acc -= x*G[a]   (a row entry that does not fit the LDS cache)
  *            5 FINOFF l = acc*G[a]; G[d] = l; if b >= 0: rc[b] = l; acc = 0
  *            6 FINDIAG t = sqrt(acc); G[d] = t; G[nnzL+b] = inv = 1/t; acc = 0 (acc <= 0 flags the sample)
  *            7 YSET acc = rhs[d] | 8 FINY G[d] = acc*inv; acc = 0

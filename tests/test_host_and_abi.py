@@ -115,7 +115,8 @@ def test_op_streams_replay_with_prefetch_semantics(spaces, m, cache):
     k, a, b, d = st["fwd"]
     real = ((k != 0) | (b != cache + 1)).sum()            # everything but the ZERO-slot padding
     n_a = (plan.a_ent >= 0).sum()
-    assert real == n_a + plan.npairs + plan.nnzL + (plan.nnzL - ops.n) + 2 * ops.n
+    n_ldx = (k == 3).sum()                                # spilled row entries cost one extra op each
+    assert real - n_ldx == n_a + plan.npairs + plan.nnzL + (plan.nnzL - ops.n) + 2 * ops.n
 
 
 def test_function_space_shim(spaces):
