@@ -56,7 +56,7 @@ struct Scratch {
 };
 
 // ---- FOM ------------------------------------------------------------------------------
-constexpr int VM_CHUNK = 16;        // ops whose global operands are fetched together, one chunk ahead
+constexpr int VM_CHUNK = 8;        // ops whose global operands are fetched together, one chunk ahead
 struct FomDev {
   int debug_phases;   // bit 0 factor+forward, 1 backward, 2 QoI (FINROM_FOM_PHASES, timing experiments only; default 7)
   int n, nnzL, xdim, n_obs, n_alist, cache_slots;

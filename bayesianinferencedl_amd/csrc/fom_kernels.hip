@@ -11,7 +11,7 @@
 // lives at  base + e*64 + lane  ("sample-blocked" layout [S/64][elements][64]).
 // The schedule is a flat op stream (bayesianinferencedl_amd/symbolic.py::build_op_streams)
 // interpreted by fom_vm_kernel; the "a" operand of a multiply-add comes from an LDS cache of the
-// row being eliminated, the "b" operand from global memory, fetched one 16-op chunk ahead.
+// row being eliminated, the "b" operand from global memory, fetched one 8-op chunk ahead.
 // Bound: HBM/L2 bandwidth (one 8-B load per multiply-add and sample, no reuse in registers).
 #include "finrom_internal.h"
 
@@ -86,7 +86,7 @@ enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
 
 // The op arrays are separate __restrict__ kernel parameters on purpose: only then can the compiler
 // prove that the stores to G never clobber them and fetch the descriptors with SCALAR loads
-// (s_load_dwordx16); through the by-value struct they become vector loads + v_readfirstlane whose
+// (s_load_dwordx8); through the by-value struct they become vector loads + v_readfirstlane whose
 // s_waitcnt vmcnt(0) drains the operand prefetch on every op.
 __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __restrict__ fA, const int* __restrict__ fKB,
                                                     const int* __restrict__ fD, const int* __restrict__ bA,
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
     const int* __restrict__ A = fA; const int* __restrict__ KB = fKB; const int* __restrict__ D = fD;
     double bufA[VM_CHUNK], bufB[VM_CHUNK];
 #define VM_EXEC_F(buf, c)                                                     \
-  int kbv[VM_CHUNK], dv[VM_CHUNK];   /* descriptors of the whole chunk: two s_load_dwordx16 */ \
+  int kbv[VM_CHUNK], dv[VM_CHUNK];   /* descriptors of the whole chunk: two s_load_dwordx8 */ \
   _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = KB[(c) * VM_CHUNK + u]; dv[u] = D[(c) * VM_CHUNK + u]; } \
   _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
     const int kb = kbv[u];                                                    \

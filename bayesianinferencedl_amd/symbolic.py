@@ -250,7 +250,7 @@ class CholeskyPlan:
 # Op streams for the device "schedule interpreter" (csrc/fom_kernels.hip::fom_vm_kernel)
 # =========================================================================================
 # The factorisation / substitution schedule is flattened into a stream of fixed-size ops that a
-# wave executes for its 64 samples.  The wave fetches the ops' global operands one CHUNK (16 ops)
+# wave executes for its 64 samples.  The wave fetches the ops' global operands one CHUNK (8 ops)
 # ahead of executing them, so a value stored while chunk c executes may be fetched no earlier than
 # for chunk c+2 (forward stream; the short backward stream is fetched chunk by chunk: c+1).  This module orders the rows (any topological order of the elimination tree is a
 # valid elimination order) and pads with NOPs so that rule always holds; tests/test_host_and_abi.py
@@ -258,7 +258,7 @@ class CholeskyPlan:
 #
 # Per-sample value space G (doubles):  [0, nnzL) entries of L (initially the assembled A values),
 # [nnzL, nnzL+n) 1/L_ii,  [nnzL+n, nnzL+2n) y then w.
-CHUNK = 16
+CHUNK = 8
 # forward kinds.  Kind 0 is the only common one and is branch-free on the device:
 #   acc -= rc[b] * G[a]        with two constant LDS slots after the row cache: NEG1 (-1.0) and ZERO (0.0),
 # so "acc = A_e" is an FMA against NEG1 (every FIN* op leaves acc = 0) and padding is an FMA against ZERO.
