@@ -60,6 +60,8 @@ SIGNATURES = {
     "finrom_rom_destroy": (None, [C.c_void_p]),
     "finrom_rom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finrom_rom_set_gradient": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, c_i32p, c_f64p]),
+    "finrom_rom_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 6),
     "finrom_subfin_avg": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "finrom_sampler_create": (C.c_int, [c_f64p, C.c_int32, C.POINTER(C.c_void_p)]),
     "finrom_sampler_destroy": (None, [C.c_void_p]),

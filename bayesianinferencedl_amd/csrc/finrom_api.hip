@@ -82,7 +82,8 @@ struct finrom_fom_s {
 struct finrom_rom_s {
   RomDev d{};
   std::vector<void*> owned;
-  Scratch Ar, Br, theta;
+  Scratch Ar, Br, theta, qtmp;
+  int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
   hipStream_t side = nullptr;          // library-owned stream for the ROM half of finrom_solve_pairs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -405,7 +406,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
 void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->Ar.release(); h->Br.release(); h->theta.release();
+  h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release();
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -432,6 +433,46 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
     if ((rc = launch_rom_solve(d, (const double*)h->Ar.p, (const double*)h->Br.p, Sc, w_r ? w_r + s0 * d.r : nullptr,
                                qoi_r ? qoi_r + s0 * d.n_obs : nullptr, A_r ? A_r + s0 * (int64_t)d.r * d.r : nullptr,
                                B_r ? B_r + s0 * d.r : nullptr, info ? info + s0 : nullptr, factor, st))) return rc;
+  }
+  return 0;
+}
+
+int finrom_rom_set_gradient(finrom_rom_t h, int32_t npairs, const int32_t* pair_p, const int32_t* pair_i, const double* G) {
+  if (!h || npairs < 0 || (npairs > 0 && (!pair_p || !pair_i || !G))) { set_error("rom_set_gradient: bad argument"); return FINROM_ERR_ARG; }
+  for (int t = 0; t < npairs; ++t)
+    if (pair_p[t] < 0 || pair_p[t] > h->d.P || pair_i[t] < 0 || pair_i[t] >= h->d.P) { set_error("rom_set_gradient: invalid pair"); return FINROM_ERR_ARG; }
+  int rc = 0;
+  if (!rc) rc = up(h->owned, &h->g_pair_p, pair_p, npairs);
+  if (!rc) rc = up(h->owned, &h->g_pair_i, pair_i, npairs);
+  if (!rc) rc = up(h->owned, &h->g_Gt, G, (size_t)npairs * h->d.r * h->d.r);
+  if (rc) return rc;
+  h->g_npairs = npairs;
+  return 0;
+}
+
+int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int32_t data_per_sample, int64_t S,
+                    double* J, double* g, double* w_r, double* qoi_r, int32_t* info, void* stream) {
+  if (!h || S < 0 || (S > 0 && (!theta || !data || !J || !g))) { set_error("rom_grad: bad argument"); return FINROM_ERR_ARG; }
+  if (h->g_npairs == 0) { set_error("rom_grad: finrom_rom_set_gradient has not been called"); return FINROM_ERR_ARG; }
+  const RomDev& d = h->d;
+  if (d.NB > 6) { set_error("rom_grad: basis size > 96 not supported yet"); return FINROM_ERR_UNSUPPORTED; }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t per_sample = ((size_t)d.rp * (d.rp + 1) / 2 + d.rp) * sizeof(double);
+  int64_t chunk = std::max<int64_t>(4, (int64_t)(((size_t)16 << 30) / per_sample) / 4 * 4);
+  for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+    const int64_t Sc = std::min(chunk, S - s0);
+    int rc;
+    if ((rc = h->Ar.reserve((size_t)Sc * (d.rp * (d.rp + 1) / 2) * sizeof(double)))) return rc;
+    if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
+    double* q = qoi_r ? qoi_r + s0 * d.n_obs : nullptr;
+    if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
+    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, 1, info ? info + s0 : nullptr, st))) return rc;
+    RomGradArgs ga;
+    ga.data = data + (data_per_sample ? s0 * d.n_obs : 0); ga.data_stride = data_per_sample ? d.n_obs : 0;
+    ga.theta = theta + s0 * d.P; ga.J = J + s0; ga.g = g + s0 * d.P;
+    ga.npairs = h->g_npairs; ga.pair_p = h->g_pair_p; ga.pair_i = h->g_pair_i; ga.Gt = h->g_Gt;
+    if ((rc = launch_rom_grad(d, (const double*)h->Ar.p, (const double*)h->Br.p, Sc, w_r ? w_r + s0 * d.r : nullptr, q,
+                              info ? info + s0 : nullptr, ga, st))) return rc;
   }
   return 0;
 }

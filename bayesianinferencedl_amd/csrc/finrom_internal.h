@@ -92,6 +92,14 @@ struct RomDev {
   const double* rhs_tv; const int* rhs_pidx; const double* rhs_f;
   const double* obs_phi;                // [n_obs x r]
 };
+struct RomGradArgs {                      // adjoint-gradient stage of rom_solve_kernel (finrom_rom_grad)
+  const double* data = nullptr; int64_t data_stride = 0;    // observations [n_obs] (stride 0) or [S x n_obs]
+  const double* theta = nullptr;                            // [S x P]
+  double* J = nullptr; double* g = nullptr;                 // [S], [S x P]
+  int npairs = 0; const int* pair_p = nullptr; const int* pair_i = nullptr; const double* Gt = nullptr;
+};
+int launch_rom_grad(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
+                    int* info, const RomGradArgs& ga, hipStream_t st);
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st);
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r,
                      double* qoi_r, double* Ar_out, double* Br_out, int* info, int factored, hipStream_t st);

@@ -479,12 +479,12 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int col_start(int k, int R) { return k * R - (k * (k - 1)) / 2; }
 
-template <bool IN_LDS, int NSET, bool FACTORED>
+template <bool IN_LDS, int NSET, bool FACTORED, bool GRAD = false>
 __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* __restrict__ Arp,
                                                        const double* __restrict__ Br, int64_t S,
                                                        double* __restrict__ w_r, double* __restrict__ qoi_r,
                                                        double* __restrict__ Ar_out, double* __restrict__ Br_out,
-                                                       int* __restrict__ info) {
+                                                       int* __restrict__ info, RomGradArgs ga = RomGradArgs()) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int r = p.r, R = p.rp, np = R * (R + 1) / 2;
   // The factor lives in LDS when it fits (R <= 176); for larger bases (r = 200) it is factored
@@ -595,25 +595,27 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
     }
     __syncthreads();
   }
-  // L y = b   (lane = row; y_k broadcast by shuffle)
-  for (int k = 0; k < R; ++k) {
-    const double yk = bcast(b, k) * invd[k];
-    const int ck = col_start(k, R) - k;
+  // b <- A_r^{-1} b through the factor:  L y = b, then L^T x = y  (lane = row; pivots broadcast by shuffle)
+  auto substitute = [&]() {
+    for (int k = 0; k < R; ++k) {
+      const double yk = bcast(b, k) * invd[k];
+      const int ck = col_start(k, R) - k;
 #pragma unroll
-    for (int u = 0; u < NSET; ++u) {
-      if (row[u] == k) b[u] = yk;
-      else if (ok[u] && row[u] > k) b[u] = fma(-Lm[ck + row[u]], yk, b[u]);
+      for (int u = 0; u < NSET; ++u) {
+        if (row[u] == k) b[u] = yk;
+        else if (ok[u] && row[u] > k) b[u] = fma(-Lm[ck + row[u]], yk, b[u]);
+      }
     }
-  }
-  // L^T x = y
-  for (int k = R - 1; k >= 0; --k) {
-    const double xk = bcast(b, k) * invd[k];
+    for (int k = R - 1; k >= 0; --k) {
+      const double xk = bcast(b, k) * invd[k];
 #pragma unroll
-    for (int u = 0; u < NSET; ++u) {
-      if (row[u] == k) b[u] = xk;
-      else if (row[u] < k) b[u] = fma(-Lm[col_start(row[u], R) + k - row[u]], xk, b[u]);
+      for (int u = 0; u < NSET; ++u) {
+        if (row[u] == k) b[u] = xk;
+        else if (row[u] < k) b[u] = fma(-Lm[col_start(row[u], R) + k - row[u]], xk, b[u]);
+      }
     }
-  }
+  };
+  substitute();
   const double nanv = __builtin_nan("");
 #pragma unroll
   for (int u = 0; u < NSET; ++u)
@@ -630,6 +632,57 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
     qoi_r[s * p.n_obs + o] = bad ? nanv : qv;
   }
   if (info != nullptr && lane == 0 && bad) atomicOr(&info[s], 2);
+
+  if constexpr (GRAD) {
+    // Adjoint gradient of J = 1/2 |data - B_obs Phi w_r|^2 with respect to the affine parameters, psi treated
+    // as theta-independent exactly as the reference does (rom/averaged_affine_ROM.py:335-356):
+    //   v_r = A_r^{-T} (B_obs Phi)^T (data - obs),   g_i = (psi v_r)^T (A_i Phi w_r) = sum_p theta_p v_r^T G_pi w_r,
+    // G_pi = (A_p Phi)^T (A_i Phi) precomputed on the host (only region pairs that share nodes are non-zero).
+    double* rs = xs + R;                           // [n_obs] residual, then v_r in vs
+    double* vs = rs + 64;
+    const double* dat = ga.data + (ga.data_stride ? s * ga.data_stride : 0);
+    double jl = 0.0;
+    for (int o = lane; o < p.n_obs; o += 64) {
+      double qv = 0.0;
+      for (int t = 0; t < r; ++t) qv = fma(p.obs_phi[o * r + t], xs[t], qv);
+      const double res = dat[o] - qv;
+      rs[o] = res;
+      jl = fma(res, res, jl);
+    }
+    for (int off = 32; off > 0; off >>= 1) jl += __shfl_xor(jl, off);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      double acc = 0.0;
+      if (row[u] < r)
+        for (int o = 0; o < p.n_obs; ++o) acc = fma(p.obs_phi[o * r + row[u]], rs[o], acc);
+      b[u] = acc;
+    }
+    substitute();
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if (ok[u]) vs[row[u]] = b[u];
+    __syncthreads();
+    double g = 0.0;                                // lane i accumulates g_i
+    for (int pi = 0; pi < ga.npairs; ++pi) {
+      const double* Gt = ga.Gt + (int64_t)pi * r * r;     // stored column by column: Gt[c * r + row]
+      double part = 0.0;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) {
+        if (row[u] < r) {
+          double t = 0.0;
+          for (int c2 = 0; c2 < r; ++c2) t = fma(Gt[c2 * r + row[u]], xs[c2], t);
+          part = fma(b[u], t, part);
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      const int pp = ga.pair_p[pi];
+      const double thp = pp == 0 ? 1.0 : ga.theta[s * p.P + pp - 1];
+      if (lane == ga.pair_i[pi]) g = fma(thp, part, g);
+    }
+    if (lane < p.P) ga.g[s * p.P + lane] = bad ? nanv : g;
+    if (lane == 0) ga.J[s] = bad ? nanv : 0.5 * jl;
+  }
 }
 
 template <bool IN_LDS, int NSET, bool FACTORED>
@@ -641,6 +694,20 @@ static int launch_solve_t(const RomDev& p, size_t lds, const double* Ar, const d
     attr_set = true;
   }
   hipLaunchKernelGGL((rom_solve_kernel<IN_LDS, NSET, FACTORED>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_rom_grad(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
+                    int* info, const RomGradArgs& ga, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_ROM_SOLVE, st);
+  const size_t lds = ((size_t)p.rp * (p.rp + 1) / 2 + 3 * (size_t)p.rp + 64) * sizeof(double);
+  const int nset = (p.rp + 63) / 64;
+  if (nset == 1) hipLaunchKernelGGL((rom_solve_kernel<true, 1, true, true>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r,
+                                    (double*)nullptr, (double*)nullptr, info, ga);
+  else hipLaunchKernelGGL((rom_solve_kernel<true, 2, true, true>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r,
+                          (double*)nullptr, (double*)nullptr, info, ga);
   FR_HIP(hipGetLastError());
   return 0;
 }

@@ -166,6 +166,27 @@ class RomEngine:
             out["A_r"] = b.out(A_r, (S, r, r)); out["B_r"] = b.out(B_r, (S, r))
         return out
 
+    def set_gradient_blocks(self, pairs, G):
+        """pairs: list of (p, i); G [npairs, r, r] with G[t] = (A_p Phi)^T (A_i Phi)  (finrom_rom_set_gradient)."""
+        pp, pi = i32([p for p, _ in pairs]), i32([i for _, i in pairs])
+        Gt = np.ascontiguousarray(np.transpose(np.asarray(G, dtype=np.float64), (0, 2, 1)))   # column by column
+        check(lib().finrom_rom_set_gradient(self._h, len(pairs), pp[1], pi[1], Gt.ctypes.data_as(_ffi.c_f64p)),
+              "finrom_rom_set_gradient")
+        self._has_grad = True
+
+    def grad(self, theta, data):
+        """theta [S, P], data [n_obs] or [S, n_obs] -> dict(J [S], g [S, P], w_r, qoi_r, info)."""
+        b = _Batch(theta, self.P)
+        S = b.S
+        data = np.ascontiguousarray(data, dtype=np.float64) if not _is_torch(data) else data
+        per_sample = 1 if data.ndim == 2 else 0
+        db = _Batch(data, self.n_obs)
+        J, Jp = b.new((S,)); g, gp = b.new((S, self.P)); w_r, wp = b.new((S, self.r))
+        qoi, qp = b.new((S, self.n_obs)); info, ip = b.new((S,), "i4")
+        check(lib().finrom_rom_grad(self._h, b.ptr, db.ptr, per_sample, S, Jp, gp, wp, qp, ip, b.stream), "finrom_rom_grad")
+        return {"J": b.out(J, (S,)), "g": b.out(g, (S, self.P)), "w_r": b.out(w_r, (S, self.r)),
+                "qoi_r": b.out(qoi, (S, self.n_obs)), "info": b.out(info, (S,), "i4")}
+
     def close(self):
         if getattr(self, "_h", None):
             lib().finrom_rom_destroy(self._h)

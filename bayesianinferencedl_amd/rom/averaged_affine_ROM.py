@@ -57,6 +57,8 @@ class AffineROMFin:
         self._avg = SubfinAverager(ops.S)
         self._plan = _plan_for(V)
         self._fom = None
+        self._grad_ready = False
+        self._psi_tables = [robin_phi] + [self.dA_dsigmak_phi[i] for i in range(9)]
 
     @property
     def dA_dsigmak(self):
@@ -81,6 +83,29 @@ class AffineROMFin:
             ops = self.ops
             self._fom = FomEngine(self._plan, ops.robin_vals, sp.csr_matrix(ops.sub_vals.T), ops.F, self.B_obs)
         return self._fom.solve(self._avg(K), want_w=want_w)
+
+    def _ensure_gradient(self):
+        """One-time: G_pi = (A_p Phi)^T (A_i Phi) for the region pairs that share nodes (finrom_rom_set_gradient)."""
+        if self._grad_ready:
+            return
+        pairs, G = [], []
+        for p in range(10):
+            for i in range(9):
+                M = self._psi_tables[p].T @ self.dA_dsigmak_phi[i]
+                if np.any(M):
+                    pairs.append((p, i)); G.append(M)
+        self._rom.set_gradient_blocks(pairs, np.stack(G))
+        self._grad_ready = True
+
+    def grad_reduced_batch(self, K, data=None, theta=None):
+        """Batched grad_reduced (:335-356): K [S, n] nodal fields (or theta [S, 9] directly) ->
+        dict(J [S], g_theta [S, 9], w_r, qoi_r, info);  dJ_dk = g_theta @ dsigma_dk."""
+        self._ensure_gradient()
+        data = self.data if data is None else data
+        th = self._avg(K) if theta is None else theta
+        res = self._rom.grad(th, data)
+        res["g_theta"] = res.pop("g")
+        return res
 
     # ---- reference call surface -------------------------------------------------------------
     def forward(self, k):
@@ -124,6 +149,15 @@ class AffineROMFin:
             qoi_vals = np.dot(self.B_obs_phi, w_r)
         self.fwd_time += (time.time() - t_i)
         return qoi_vals
+
+    def grad_reduced(self, k):
+        t_i = time.time()
+        res = self.grad_reduced_batch(as_nodal(k)[None, :])
+        if res["info"][0]:
+            raise np.linalg.LinAlgError("reduced operator not positive definite")
+        dJ_dk = np.dot(res["g_theta"][0], self.dsigma_dk)       # [9] x [9, n]  (:349-351)
+        self.rom_grad_time += (time.time() - t_i)
+        return dJ_dk, float(res["J"][0])
 
     def set_data(self, data):
         self.data = data

@@ -160,6 +160,20 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S,
                      double* w_r, double* qoi_r, double* A_r, double* B_r,
                      int32_t* info, void* stream);
 
+/* ---- ROM adjoint gradient (AffineROMFin.grad_reduced, rom/averaged_affine_ROM.py:335-356) ---------- *
+ * J = 1/2 |data - (B_obs Phi) w_r|^2 and its gradient with respect to the P affine parameters,
+ *   g_i = (psi v_r)^T (A_i Phi w_r),   v_r = A_r^{-T} (B_obs Phi)^T (data - (B_obs Phi) w_r),
+ * with psi treated as theta-independent exactly as the reference does.  (The reference then maps g to the
+ * nodal field through dsigma_dk: dJ_dk = g^T S, a [P x n] product left to the caller.)
+ * finrom_rom_set_gradient installs the host-precomputed blocks G_pi = (A_p Phi)^T (A_i Phi), one r x r matrix
+ * per listed pair (p in 0..P with 0 = constant term, i in 0..P-1), each stored COLUMN by column.
+ * finrom_rom_grad: theta [S x P], data [n_obs] (data_per_sample = 0) or [S x n_obs] (1) ->
+ * J [S], g [S x P]; optional w_r [S x r], qoi_r [S x n_obs]; info as for finrom_rom_solve.  r <= 96. */
+int finrom_rom_set_gradient(finrom_rom_t h, int32_t npairs, const int32_t* pair_p, const int32_t* pair_i,
+                            const double* G);
+int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int32_t data_per_sample,
+                    int64_t S, double* J, double* g, double* w_r, double* qoi_r, int32_t* info, void* stream);
+
 /* ---- sub-fin averages  theta = S k  (fom :466-480, rom :404-418) -------------------- *
  * Sop is the dense [P x n] averaging operator on the device (finrom_malloc + h2d). */
 int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n,
