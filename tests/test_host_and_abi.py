@@ -180,3 +180,15 @@ dist.destroy_process_group()
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def test_reference_import_paths_resolve():
+    """`from fom.forward_solve import Fin` etc. (the reference's import paths) resolve to the HIP-backed classes."""
+    from fom.forward_solve import Fin
+    from fom.thermal_fin import get_space
+    from rom.averaged_affine_ROM import AffineROMFin
+    from bayesian_inference.gaussian_field import make_cov_chol
+    from deep_learning.generate_fin_dataset import gen_affine_avg_rom_dataset
+    import bayesianinferencedl_amd.fom.forward_solve as impl
+    assert Fin is impl.Fin and callable(get_space) and callable(make_cov_chol) and callable(gen_affine_avg_rom_dataset)
+    assert AffineROMFin.__module__ == "bayesianinferencedl_amd.rom.averaged_affine_ROM"
