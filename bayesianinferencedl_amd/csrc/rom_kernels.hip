@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t s = (int64_t)blockIdx.x * (4 / NW) + wave / NW;
   if (s >= S) return;                       // no block-wide barrier below
-  __builtin_amdgcn_s_setprio(3);            // MFMA-paced waves win issue arbitration over co-resident FOM waves
+  // (no s_setprio: measured)
   if (lane == 0) th[wave][0] = 1.0;
   if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
   __builtin_amdgcn_wave_barrier();
