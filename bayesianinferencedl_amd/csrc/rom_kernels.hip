@@ -106,7 +106,7 @@ __device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, i
       bad |= !(piv > 0.0);
       double rinv = __builtin_amdgcn_rsq(piv);                 // 1/sqrt: hardware estimate + Newton steps
 #pragma unroll
-      for (int it = 0; it < 4; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+      for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
       const double sc = (q == qs) ? rinv : 1.0;
 #pragma unroll
       for (int tj = kb; tj < NB; ++tj) acc[dg + (tj - kb)][gs] *= sc;     // row st of U is final
