@@ -29,6 +29,13 @@ class FomDesc(C.Structure):
                 ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p), ("perm", c_i32p)]
 
 
+class FomGradDesc(C.Structure):
+    _fields_ = [("nops_res", C.c_int32),
+                ("res_kind", c_i32p), ("res_a", c_i32p), ("res_b", c_i32p), ("res_d", c_i32p),
+                ("bt_ptr", c_i32p), ("bt_obs", c_i32p), ("bt_w", c_f64p),
+                ("g_ptr", c_i32p), ("g_a", c_i32p), ("g_b", c_i32p), ("g_w", c_f64p)]
+
+
 class RomDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("r", C.c_int32), ("P", C.c_int32), ("n_obs", C.c_int32),
                 ("nterms", C.c_int32),
@@ -56,6 +63,8 @@ SIGNATURES = {
     "finrom_fom_create": (C.c_int, [C.POINTER(FomDesc), C.POINTER(C.c_void_p)]),
     "finrom_fom_destroy": (None, [C.c_void_p]),
     "finrom_fom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finrom_fom_set_gradient": (C.c_int, [C.c_void_p, C.POINTER(FomGradDesc)]),
+    "finrom_fom_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 5),
     "finrom_rom_create": (C.c_int, [C.POINTER(RomDesc), C.POINTER(C.c_void_p)]),
     "finrom_rom_destroy": (None, [C.c_void_p]),
     "finrom_rom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

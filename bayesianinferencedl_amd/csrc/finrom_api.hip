@@ -77,7 +77,7 @@ using namespace finrom;
 struct finrom_fom_s {
   FomDev d{};
   std::vector<void*> owned;
-  Scratch xT, Gw;
+  Scratch xT, Gw, gradT, qtmp;
 };
 struct finrom_rom_s {
   RomDev d{};
@@ -219,6 +219,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   d.gsize = gsize;
   d.nchunks_fwd = a->nops_fwd / VM_CHUNK - 2; d.nchunks_bwd = a->nops_bwd / VM_CHUNK - 2;
   d.debug_phases = 7;
+  d.has_grad = 0; d.nchunks_res = 0;
   if (const char* ph = getenv("FINROM_FOM_PHASES")) d.debug_phases = atoi(ph);
   std::vector<int> fkb(a->nops_fwd), bkb(a->nops_bwd);
   for (int t = 0; t < a->nops_fwd; ++t) fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8);
@@ -249,7 +250,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
 void finrom_fom_destroy(finrom_fom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->xT.release(); h->Gw.release();
+  h->xT.release(); h->Gw.release(); h->gradT.release(); h->qtmp.release();
   delete h;
 }
 
@@ -271,6 +272,78 @@ int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, do
     if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Gw.p,
                          qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
     if (w && (rc = launch_unpack_w(d, (const double*)h->Gw.p, Sc, w + s0 * d.n, st))) return rc;
+  }
+  return 0;
+}
+
+int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* a) {
+  if (!h || !a || a->nops_res < VM_CHUNK || a->nops_res % VM_CHUNK) { set_error("fom_set_gradient: bad argument"); return FINROM_ERR_ARG; }
+  FomDev& d = h->d;
+  const int n = d.n, nnzL = d.nnzL, gsize = nnzL + 3 * n;
+  auto bad = [&](const char* what) { set_error(std::string("fom_set_gradient: invalid ") + what); return FINROM_ERR_ARG; };
+  {
+    std::vector<int> stored(gsize, -10);
+    auto need1 = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 1 <= c; };
+    for (int t = 0; t < a->nops_res; ++t) {
+      const int k = a->res_kind[t], A = a->res_a[t], B = a->res_b[t], D = a->res_d[t], c = t / VM_CHUNK;
+      switch (k) {
+        case 0: break;
+        case 1: if (!need1(A, c) || !need1(B, c)) return bad("WFMA op"); break;
+        case 3: if (!need1(A, c)) return bad("WSET op"); break;
+        case 5: if (!need1(A, c) || D < nnzL + 2 * n || D >= gsize) return bad("WFIN op"); stored[D] = c; break;
+        default: return bad("op kind");
+      }
+    }
+  }
+  if (a->bt_ptr[0] != 0) return bad("bt_ptr");
+  for (int i = 0; i < n; ++i) if (a->bt_ptr[i + 1] < a->bt_ptr[i]) return bad("bt_ptr");
+  for (int t = 0; t < a->bt_ptr[n]; ++t) if (a->bt_obs[t] < 0 || a->bt_obs[t] >= d.n_obs) return bad("bt_obs");
+  if (a->g_ptr[0] != 0) return bad("g_ptr");
+  for (int j = 0; j < d.xdim; ++j) if (a->g_ptr[j + 1] < a->g_ptr[j]) return bad("g_ptr");
+  for (int t = 0; t < a->g_ptr[d.xdim]; ++t) if (a->g_a[t] < 0 || a->g_a[t] >= n || a->g_b[t] < 0 || a->g_b[t] >= n) return bad("g_a/g_b");
+  std::vector<int> rkb(a->nops_res);
+  for (int t = 0; t < a->nops_res; ++t) rkb[t] = a->res_kind[t] | ((a->res_b[t] + 1) << 8);
+  int rc = 0;
+  if (!rc) rc = up(h->owned, &d.r_a, a->res_a, a->nops_res);
+  if (!rc) rc = up(h->owned, &d.r_kb, rkb.data(), rkb.size());
+  if (!rc) rc = up(h->owned, &d.r_d, a->res_d, a->nops_res);
+  if (!rc) rc = up(h->owned, &d.bt_ptr, a->bt_ptr, n + 1);
+  if (!rc) rc = up(h->owned, &d.bt_obs, a->bt_obs, a->bt_ptr[n]);
+  if (!rc) rc = up(h->owned, &d.bt_w, a->bt_w, a->bt_ptr[n]);
+  if (!rc) rc = up(h->owned, &d.g_ptr, a->g_ptr, d.xdim + 1);
+  if (!rc) rc = up(h->owned, &d.g_a, a->g_a, a->g_ptr[d.xdim]);
+  if (!rc) rc = up(h->owned, &d.g_b, a->g_b, a->g_ptr[d.xdim]);
+  if (!rc) rc = up(h->owned, &d.g_w, a->g_w, a->g_ptr[d.xdim]);
+  if (rc) return rc;
+  d.nchunks_res = a->nops_res / VM_CHUNK;
+  d.has_grad = 1;
+  d.gsize = gsize;                       // value vector grows by the adjoint region
+  return 0;
+}
+
+int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int32_t data_per_sample, int64_t S,
+                        double* grad, double* J, double* qoi, int32_t* info, void* stream) {
+  if (!h || S < 0 || (S > 0 && (!x || !data || !grad || !J))) { set_error("fom_gradient: bad argument"); return FINROM_ERR_ARG; }
+  if (!h->d.has_grad) { set_error("fom_gradient: finrom_fom_set_gradient has not been called"); return FINROM_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  const FomDev& d = h->d;
+  const size_t per_sample = ((size_t)d.gsize + 2 * d.xdim) * sizeof(double);
+  int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
+  chunk = std::max<int64_t>(64, chunk / 64 * 64);
+  for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+    const int64_t Sc = std::min(chunk, S - s0);
+    const int64_t nblk = (Sc + 63) / 64;
+    int rc;
+    if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+    if ((rc = h->Gw.reserve((size_t)nblk * d.gsize * 64 * sizeof(double)))) return rc;
+    if ((rc = h->gradT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+    double* q = qoi ? qoi + s0 * d.n_obs : nullptr;
+    if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
+    if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
+    if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Gw.p, q, info ? info + s0 : nullptr, st))) return rc;
+    if ((rc = launch_fom_adjoint(d, nblk, Sc, (double*)h->Gw.p, q, data + (data_per_sample ? s0 * d.n_obs : 0),
+                                 data_per_sample ? d.n_obs : 0, (double*)h->gradT.p, J + s0, st))) return rc;
+    if ((rc = launch_unpack((const double*)h->gradT.p, Sc, d.xdim, d.xdim, 0, nullptr, grad + s0 * d.xdim, st))) return rc;
   }
   return 0;
 }

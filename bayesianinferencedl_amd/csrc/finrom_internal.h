@@ -67,7 +67,15 @@ struct FomDev {
   const int* f_a; const int* f_kb; const int* f_d;     // forward stream: load index, kind | (b+1) << 8, d
   const int* b_a; const int* b_kb; const int* b_d;     // backward stream
   const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
+  // adjoint gradient (finrom_fom_set_gradient); the value vector then has a 4th region v at nnzL + 2n
+  int has_grad, nchunks_res;
+  const int* r_a; const int* r_kb; const int* r_d;
+  const int* bt_ptr; const int* bt_obs; const double* bt_w;
+  const int* g_ptr; const int* g_a; const int* g_b; const double* g_w;
 };
+int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, const double* qoi, const double* data,
+                       int64_t data_stride, double* gradT, double* J, hipStream_t st);
+int launch_unpack(const double* srcT, int64_t S, int d, int64_t blk_stride, int off, const int* perm, double* dst, hipStream_t st);
 int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st);
 int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st);
 int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st);

@@ -228,10 +228,101 @@ int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, doubl
 }
 
 // ---------------------------------------------------------------------------------------
-// unpack: blocked, permuted w -> row-major w[S][n] in the caller's dof order
+// adjoint gradient (Fin.gradient, fom/forward_solve.py:293-322), after fom_vm_kernel left L, 1/L_ii and w in G:
+//   r = B_obs w - data,  J = |r|^2 / 2,  b = -B_obs^T r,  v = A^{-1} b (stored factor, "solve again" stream),
+//   grad_j = sum_(a,b) dA_ab/dx_j * v_a * w_b.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void fom_adjoint_kernel(FomDev p, const int* __restrict__ rA, const int* __restrict__ rKB,
+                                                         const int* __restrict__ rD, const int* __restrict__ bt_ptr,
+                                                         const int* __restrict__ bt_obs, const double* __restrict__ bt_w,
+                                                         const int* __restrict__ g_ptr, const int* __restrict__ g_a,
+                                                         const int* __restrict__ g_b, const double* __restrict__ g_w,
+                                                         double* __restrict__ Gw, int64_t S,
+                                                         const double* __restrict__ qoi, const double* __restrict__ data,
+                                                         int64_t data_stride, double* __restrict__ gradT,
+                                                         double* __restrict__ Jout) {
+  extern __shared__ __attribute__((aligned(16))) double rsd[];    // [n_obs][64] residuals
+  const int lane = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  double* G = Gw + blk * (int64_t)p.gsize * 64 + lane;
+  const int ZV = p.nnzL + p.n, VV = p.nnzL + 2 * p.n;
+  int64_t s = blk * 64 + lane;
+  const bool live = s < S;
+  if (!live) s = S - 1;                                  // tail lanes replicate the last sample (as pack_kernel does)
+  double* rs = rsd + lane;
+  double jl = 0.0;
+  for (int o = 0; o < p.n_obs; ++o) {
+    const double r = qoi[s * p.n_obs + o] - data[(data_stride ? s * data_stride : 0) + o];
+    rs[o * 64] = r;
+    jl = fma(r, r, jl);
+  }
+  for (int i = 0; i < p.n; ++i) {                        // b = -B_obs^T r
+    double acc = 0.0;
+    for (int t = bt_ptr[i], t1 = bt_ptr[i + 1]; t < t1; ++t) acc = fma(-bt_w[t], rs[bt_obs[t] * 64], acc);
+    G[(int64_t)(VV + i) * 64] = acc;
+  }
+  // v = (L L^T)^{-1} b : same interpreter as the backward stream (both operands from global, chunk by chunk)
+  {
+    double acc = 0.0, a1[VM_CHUNK], b1[VM_CHUNK];
+    for (int c = 0; c < p.nchunks_res; ++c) {
+      int kbv[VM_CHUNK], dv[VM_CHUNK];
+#pragma unroll
+      for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = rKB[c * VM_CHUNK + u]; dv[u] = rD[c * VM_CHUNK + u]; }
+#pragma unroll
+      for (int u = 0; u < VM_CHUNK; ++u) {
+        const int a_ = rA[c * VM_CHUNK + u];
+        const int b_ = (kbv[u] >> 8) - 1;
+        a1[u] = G[(int64_t)(a_ < 0 ? 0 : a_) * 64];
+        b1[u] = G[(int64_t)(b_ < 0 ? 0 : b_) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < VM_CHUNK; ++u) {
+        const int kind = kbv[u] & 255;
+        if (kind == B_WFMA) acc = fma(-a1[u], b1[u], acc);
+        else if (kind == B_WSET) acc = a1[u];
+        else if (kind == B_WFIN) G[(int64_t)dv[u] * 64] = acc * a1[u];
+      }
+    }
+  }
+  // grad_j = sum dA_ab/dx_j v_a w_b, loads batched by 4 pairs
+  for (int j = 0; j < p.xdim; ++j) {
+    double g0 = 0.0, g1 = 0.0;
+    const int t0 = g_ptr[j], t1 = g_ptr[j + 1];
+    for (int t = t0; t < t1; t += 4) {
+      double va[4], wb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int tt = (t + u < t1) ? t + u : t1 - 1;
+        va[u] = G[(int64_t)(VV + g_a[tt]) * 64];
+        wb[u] = G[(int64_t)(ZV + g_b[tt]) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u += 2) {
+        g0 = fma((t + u < t1) ? g_w[t + u] : 0.0, va[u] * wb[u], g0);
+        g1 = fma((t + u + 1 < t1) ? g_w[t + u + 1] : 0.0, va[u + 1] * wb[u + 1], g1);
+      }
+    }
+    gradT[(blk * p.xdim + j) * 64 + lane] = g0 + g1;      // NaN propagates from a failed factorisation
+  }
+  if (live) Jout[s] = 0.5 * jl;
+}
+
+int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, const double* qoi, const double* data,
+                       int64_t data_stride, double* gradT, double* J, hipStream_t st) {
+  if (nblk == 0) return 0;
+  ScopedKernelTimer t(K_FOM, st);
+  const size_t lds = (size_t)(p.n_obs > 0 ? p.n_obs : 1) * 64 * sizeof(double);
+  hipLaunchKernelGGL(fom_adjoint_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, p.r_a, p.r_kb, p.r_d, p.bt_ptr, p.bt_obs,
+                     p.bt_w, p.g_ptr, p.g_a, p.g_b, p.g_w, Gw, S, qoi, data, data_stride, gradT, J);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// unpack: blocked (optionally permuted) values -> row-major [S][d] in the caller's order
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void unpack_w_kernel(const double* __restrict__ Gw, const int* __restrict__ perm,
-                                                       int n, int gsize, int woff, int64_t S, double* __restrict__ w) {
+                                                       int n, int64_t gsize, int woff, int64_t S, double* __restrict__ w) {
   __shared__ double tile[64][65];
   const int64_t blk = blockIdx.x;
   const int i0 = blockIdx.y * 64;
@@ -242,21 +333,25 @@ __global__ __launch_bounds__(256) void unpack_w_kernel(const double* __restrict_
   }
   __syncthreads();
   const int i = i0 + tx;
-  const int col = (i < n) ? perm[i] : 0;
+  const int col = (i < n) ? (perm != nullptr ? perm[i] : i) : 0;
   for (int sl = ty; sl < 64; sl += 4) {
     int64_t s = blk * 64 + sl;
     if (s < S && i < n) w[s * n + col] = tile[tx][sl];
   }
 }
 
-int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st) {
+int launch_unpack(const double* srcT, int64_t S, int d, int64_t blk_stride, int off, const int* perm, double* dst, hipStream_t st) {
   int64_t nblk = (S + 63) / 64;
   if (nblk == 0) return 0;
   ScopedKernelTimer t(K_UNPACK_W, st);
-  dim3 grid((unsigned)nblk, (unsigned)((p.n + 63) / 64));
-  hipLaunchKernelGGL(unpack_w_kernel, grid, dim3(256), 0, st, Gw, p.perm, p.n, p.gsize, p.nnzL + p.n, S, w);
+  dim3 grid((unsigned)nblk, (unsigned)((d + 63) / 64));
+  hipLaunchKernelGGL(unpack_w_kernel, grid, dim3(256), 0, st, srcT, perm, d, blk_stride, off, S, dst);
   FR_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st) {
+  return launch_unpack(Gw, S, p.n, p.gsize, p.nnzL + p.n, p.perm, w, st);
 }
 
 }  // namespace finrom

@@ -10,7 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _ffi
-from ._ffi import DeviceBuffer, FomDesc, RomDesc, check, f64, i32, lib
+from ._ffi import DeviceBuffer, FomDesc, FomGradDesc, RomDesc, check, f64, i32, lib
 
 
 ROW_CACHE_SLOTS = 42     # LDS row cache of the FOM interpreter: (42+2) x 512 B = 22 KiB per wave, 7 waves per CU (154 KiB)
@@ -69,13 +69,15 @@ class FomEngine:
     """Batched ``A(x) w = F`` + QoI (finrom_fom_*).  ``c0``/``W`` define the sparse-affine
     value map on the CSR pattern of A (see include/finrom.h)."""
 
-    def __init__(self, plan, c0_csr, W_csr, rhs, B_obs):
+    def __init__(self, plan, c0_csr, W_csr, rhs, B_obs, pattern=None):
         self.plan = plan
         self.n = plan.n
         W_csr = sp.csr_matrix(W_csr)
         self.xdim = W_csr.shape[1]
+        self._W, self._pattern, self._grad = W_csr, pattern, False
         c0, aptr, aidx, aw = plan.entry_table(c0_csr, W_csr)
         Bp = sp.csr_matrix(np.asarray(B_obs)[:, plan.perm]) if not sp.issparse(B_obs) else sp.csr_matrix(B_obs)[:, plan.perm]
+        self._Bp = Bp
         optr, oidx, ow = _csr_rows(Bp)
         self.n_obs = Bp.shape[0]
         keep = []
@@ -107,6 +109,52 @@ class FomEngine:
         w, wp = (b.new((S, self.n)) if want_w else (None, None))
         check(lib().finrom_fom_solve(self._h, b.ptr, S, qp, wp, ip, b.stream), "finrom_fom_solve")
         return {"qoi": b.out(qoi, (S, self.n_obs)), "w": b.out(w, (S, self.n)) if want_w else None,
+                "info": b.out(info, (S,), "i4")}
+
+    def _enable_gradient(self):
+        """One-time tables of the adjoint gradient (finrom_fom_set_gradient)."""
+        if self._grad:
+            return
+        if self._pattern is None:
+            raise ValueError("FomEngine needs the CSR pattern of A for gradients")
+        from .symbolic import build_resolve_stream
+        plan, n = self.plan, self.n
+        rk, ra, rb, rd = build_resolve_stream(plan, plan.nnzL + 2 * n)
+        Bt = sp.csr_matrix(self._Bp.T)                       # [n(permuted) x n_obs]
+        Bt.sort_indices()
+        indptr, indices = np.asarray(self._pattern[0]), np.asarray(self._pattern[1])
+        e_row = np.repeat(np.arange(n), np.diff(indptr))
+        Wt = sp.csc_matrix(self._W)                          # columns = parameters
+        g_ptr = Wt.indptr.astype(np.int32)
+        ent = Wt.indices
+        g_a = plan.iperm[e_row[ent]].astype(np.int32)        # row of the entry, permuted
+        g_b = plan.iperm[indices[ent]].astype(np.int32)      # column of the entry, permuted
+        keep = []
+
+        def I(a):
+            a, p = i32(a); keep.append(a); return p
+
+        def D(a):
+            a, p = f64(a); keep.append(a); return p
+
+        d = FomGradDesc(nops_res=len(rk), res_kind=I(rk), res_a=I(ra), res_b=I(rb), res_d=I(rd),
+                        bt_ptr=I(Bt.indptr), bt_obs=I(Bt.indices), bt_w=D(Bt.data),
+                        g_ptr=I(g_ptr), g_a=I(g_a), g_b=I(g_b), g_w=D(Wt.data))
+        check(lib().finrom_fom_set_gradient(self._h, C.byref(d)), "finrom_fom_set_gradient")
+        self._grad = True
+
+    def gradient(self, X, data):
+        """X [S, xdim], data [n_obs] or [S, n_obs] -> dict(grad [S, xdim], J [S], qoi, info)
+        (Fin.gradient, fom/forward_solve.py:293-322, for a batch)."""
+        self._enable_gradient()
+        b = _Batch(X, self.xdim)
+        S = b.S
+        data = data if _is_torch(data) else np.ascontiguousarray(data, dtype=np.float64)
+        per_sample = 1 if data.ndim == 2 else 0
+        db = _Batch(data, self.n_obs)
+        grad, gp = b.new((S, self.xdim)); J, Jp = b.new((S,)); qoi, qp = b.new((S, self.n_obs)); info, ip = b.new((S,), "i4")
+        check(lib().finrom_fom_gradient(self._h, b.ptr, db.ptr, per_sample, S, gp, Jp, qp, ip, b.stream), "finrom_fom_gradient")
+        return {"grad": b.out(grad, (S, self.xdim)), "J": b.out(J, (S,)), "qoi": b.out(qoi, (S, self.n_obs)),
                 "info": b.out(info, (S,), "i4")}
 
     def close(self):

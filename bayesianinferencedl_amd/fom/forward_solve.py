@@ -70,7 +70,7 @@ class Fin:
                 W = sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9 @ ops.E59))
             else:
                 raise KeyError(kind)
-            self._engines[kind] = FomEngine(self._plan, ops.robin_vals, W, ops.F, self.B_obs)
+            self._engines[kind] = FomEngine(self._plan, ops.robin_vals, W, ops.F, self.B_obs, pattern=(ops.indptr, ops.indices))
         return self._engines[kind]
 
     # ---- batched extensions (new, additive) ---------------------------------------------
@@ -78,6 +78,11 @@ class Fin:
         """K [S, n] nodal fields (or [S, 9] / [S, 5] fin conductivities with params='nine'/'five')
         -> dict(qoi [S, n_obs], w [S, n] | None, info [S])."""
         return self._engine(params or "field").solve(K, want_w=want_w)
+
+    def gradient_batch(self, K, data, params=None):
+        """Batched adjoint gradient of J = 1/2 |B_obs w - data|^2 (:293-322): K [S, n] fields (or per-fin
+        conductivities with params='nine'/'five') -> dict(grad [S, xdim], J [S], qoi, info)."""
+        return self._engine(params or "field").gradient(K, data)
 
     def subfin_avg_batch(self, K):
         if self._avg is None:
@@ -93,6 +98,13 @@ class Fin:
         z = Function(self.V, res["w"][0])
         z._qoi = res["qoi"][0].copy()
         return z, None, None, None, None
+
+    def gradient(self, k, data):
+        self._k.assign(k)
+        res = self.gradient_batch(as_nodal(self._k)[None, :], np.asarray(data, dtype=np.float64))
+        if res["info"][0]:
+            raise np.linalg.LinAlgError("FOM operator not positive definite for this conductivity")
+        return res["grad"][0]
 
     def forward_five_param(self, k_s):
         return self.forward(self.five_param_to_function(k_s))

@@ -428,6 +428,52 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
     return {"fwd": fwd, "bwd": bwd, "a_list": a_list}
 
 
+def build_resolve_stream(plan: "CholeskyPlan", base: int):
+    """Op stream (backward-interpreter format: WSET / WFMA / WFIN, both operands from global memory) that
+    solves  L L^T v = b  with the STORED factor for a second right-hand side living in the value region
+    [base, base + n) (b on entry, v on exit): forward substitution row by row, then backward substitution.
+    Used for the adjoint solve of Fin.gradient (fom/forward_solve.py:293-322; A is symmetric, so the adjoint
+    operator `_adj_F` is the same factor)."""
+    n, nnzL = plan.n, plan.nnzL
+    row_ptr, ent_col = plan.row_ptr.astype(np.int64), plan.ent_col.astype(np.int64)
+    col_ptr = plan.col_ptr.astype(np.int64)
+    IV = nnzL
+    em = _Emitter(nnzL + 2 * n + (base - (nnzL + n)) + n, distance=1)
+    # forward: rows in elimination order (a valid order; padding covers the chains)
+    for i in range(n):
+        e0, e1 = row_ptr[i], row_ptr[i + 1]
+        em.emit(OPB_WSET, a=base + i, loads=(base + i,))
+        for e in range(e0, e1 - 1):
+            yk = base + int(ent_col[e])
+            em.emit(OPB_WFMA, a=int(e), b=yk, loads=(yk,))
+        em.emit(OPB_WFIN, a=IV + i, d=base + i, stores=(base + i,))
+    for i in range(n - 1, -1, -1):
+        em.emit(OPB_WSET, a=base + i, loads=(base + i,))
+        for c in range(col_ptr[i], col_ptr[i + 1]):
+            wr = base + int(plan.col_row[c])
+            em.emit(OPB_WFMA, a=int(plan.col_ent[c]), b=wr, loads=(wr,))
+        em.emit(OPB_WFIN, a=IV + i, d=base + i, stores=(base + i,))
+    return em.arrays()
+
+
+def replay_resolve_stream(plan, stream, Lvals, invd, b_perm, base):
+    """NumPy replay of build_resolve_stream (chunk fetched right before it executes)."""
+    kind, a, b, d = stream
+    n, nnzL = plan.n, plan.nnzL
+    G = np.zeros(base + n)
+    G[:nnzL] = Lvals; G[nnzL:nnzL + n] = invd; G[base:] = b_perm
+    acc = 0.0
+    for c in range(len(kind) // CHUNK):
+        sl = slice(c * CHUNK, (c + 1) * CHUNK)
+        va = G[np.maximum(a[sl], 0)].copy(); vb = G[np.maximum(b[sl], 0)].copy()
+        for u in range(CHUNK):
+            t = c * CHUNK + u
+            if kind[t] == OPB_WSET: acc = va[u]
+            elif kind[t] == OPB_WFMA: acc -= va[u] * vb[u]
+            elif kind[t] == OPB_WFIN: G[d[t]] = acc * va[u]
+    return G[base:].copy()
+
+
 def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
     """NumPy replay of the device interpreter WITH its prefetch semantics (operands of chunk c+1 are
     read before chunk c executes); A_entries[e] = assembled A value of entry e (0 for fill).

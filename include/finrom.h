@@ -128,6 +128,25 @@ void finrom_fom_destroy(finrom_fom_t h);
 int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S,
                      double* qoi, double* w, int32_t* info, void* stream);
 
+/* ---- FOM adjoint gradient (Fin.gradient, fom/forward_solve.py:293-322) ---------------------- *
+ * J = 1/2 |B_obs w - data|^2 and dJ/dx_j = v^T (dA/dx_j) w with the adjoint v = -A^{-1} B_obs^T (B_obs w - data)
+ * (A is symmetric: the reference's `_adj_F` is the same operator, so the stored factor is reused through a
+ * second op stream).  finrom_fom_set_gradient installs, all over PERMUTED dofs:
+ *   res_*    the "solve again" op stream (backward-interpreter op format, value region [nnzL+2n, nnzL+3n)),
+ *   bt_*     B_obs^T as CSR by dof  (row i: observation indices and weights),
+ *   g_*      for every parameter j the list of (row a, column b, weight dA_ab/dx_j) triples.
+ * finrom_fom_gradient: x [S x xdim], data [n_obs] (data_per_sample = 0) or [S x n_obs] ->
+ * grad [S x xdim], J [S], optional qoi [S x n_obs]; info as for finrom_fom_solve. */
+typedef struct {
+  int32_t nops_res;
+  const int32_t* res_kind; const int32_t* res_a; const int32_t* res_b; const int32_t* res_d;
+  const int32_t* bt_ptr; const int32_t* bt_obs; const double* bt_w;     /* [n+1], [nnz(B_obs)] */
+  const int32_t* g_ptr; const int32_t* g_a; const int32_t* g_b; const double* g_w;   /* [xdim+1], [g_ptr[xdim]] */
+} finrom_fom_grad_desc;
+int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* desc);
+int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int32_t data_per_sample, int64_t S,
+                        double* grad, double* J, double* qoi, int32_t* info, void* stream);
+
 /* ---- ROM: batched LSPG reduced solve ------------------------------------------------- *
  * Replaces AffineROMFin.forward_nine_param_reduced + .qoi_reduced
  * (rom/averaged_affine_ROM.py:278-310, 323-333):

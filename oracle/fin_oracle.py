@@ -277,6 +277,20 @@ class FinOracle:
         A = self.prob.assemble_fom(np.asarray(k_nodal, float))
         return spl.spsolve(A.tocsc(), self.B)              # DOLFIN default: sparse LU
 
+    def gradient(self, k_nodal, data):                       # :293-322 (adjoint method)
+        A = self.prob.assemble_fom(np.asarray(k_nodal, float)).tocsc()
+        z = spl.spsolve(A, self.B)
+        pred_obs = self.B_obs @ z
+        adj_RHS = -(pred_obs - data) @ self.B_obs
+        v = spl.spsolve(A, adj_RHS)                          # A_adj == A (symmetric form)
+        # grad_j = int phi_j grad z . grad v dx = sum_cells (1/3) v_c^T K_c z_c
+        g = np.zeros(self.prob.n)
+        for c, tri in enumerate(self.prob.cells):
+            val = v[tri] @ self.prob.Kc[c] @ z[tri] / 3.0
+            for t in tri:
+                g[t] += val
+        return g
+
     def qoi_operator(self, w):                               # :408-412
         return self.B_obs @ w
 

@@ -181,3 +181,41 @@ def test_rom_adjoint_gradient_parity(problems, spaces, m, r):
     g_ref, J_ref = ro.grad_reduced(K[4])
     assert abs(res2["J"][4] - J_ref) < 1e-10 * abs(J_ref)
     assert np.linalg.norm(res2["g"][4] @ rom.dsigma_dk - g_ref) < 1e-8 * np.linalg.norm(g_ref)
+
+
+def test_fom_adjoint_gradient_parity(problems, spaces):
+    """Fin.gradient (fom/forward_solve.py:293-322) against the oracle restatement, plus a directional
+    finite-difference check of J (the reference's own kind of test: bayesian_inference/gradient_fd_test.py)."""
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.fem import Function
+    for m, S in ((4, 70), (12, 66)):
+        prob = problems(m); V = spaces(m)
+        fo = O.FinOracle(prob)
+        fin = Fin(V)
+        rng = np.random.default_rng(12)
+        K = np.exp(0.3 * rng.standard_normal((S, prob.n)))
+        data = rng.uniform(0.1, 0.6, 9)
+        res = fin.gradient_batch(K, data)
+        assert (res["info"] == 0).all()
+        for s in (0, S - 1):
+            g_ref = fo.gradient(K[s], data)
+            assert np.linalg.norm(res["grad"][s] - g_ref) < 1e-9 * np.linalg.norm(g_ref)
+            J_ref = 0.5 * np.sum((fo.qoi_operator(fo.forward(K[s])) - data) ** 2)
+            assert abs(res["J"][s] - J_ref) < 1e-10 * J_ref
+        # finite differences of the device J along a random direction
+        d = rng.standard_normal(prob.n); d /= np.linalg.norm(d)
+        h = 1e-5
+        Jp = fin.gradient_batch((K[0] + h * d)[None, :], data)["J"][0]
+        Jm = fin.gradient_batch((K[0] - h * d)[None, :], data)["J"][0]
+        assert abs((Jp - Jm) / (2 * h) - res["grad"][0] @ d) < 1e-6 * abs(res["grad"][0] @ d) + 1e-12
+        # scalar call surface
+        z = Function(V); z.vector().set_local(K[1])
+        assert np.linalg.norm(fin.gradient(z, data) - res["grad"][1]) < 1e-13 * np.linalg.norm(res["grad"][1])
+    # per-fin parametrisation: chain rule through the interpolation
+    fin = Fin(spaces(12)); prob = problems(12); fo = O.FinOracle(prob)
+    k9 = np.random.default_rng(13).uniform(0.5, 3.0, (3, 9))
+    data = np.full(9, 0.3)
+    r9 = fin.gradient_batch(k9, data, params="nine")
+    g_field = fo.gradient(fo.nine_param_to_function(k9[2]), data)
+    N9 = spaces(12).operators().N9
+    assert np.linalg.norm(r9["grad"][2] - g_field @ N9) < 1e-9 * np.linalg.norm(g_field @ N9)
