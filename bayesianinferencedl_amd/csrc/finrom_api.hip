@@ -500,12 +500,18 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
     if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
     // A_r is factored inside the projection kernel (in registers, MFMA trailing updates) unless the caller
     // wants A_r itself back (the state the reference's gradients use) or the basis needs more than one wave
-    const int factor = ((A_r == nullptr || getenv("FINROM_DEBUG_RETURN_FACTOR") != nullptr) && d.NB <= 6 &&
-                        getenv("FINROM_NO_FUSED_CHOL") == nullptr) ? 1 : 0;   // debug: A_r output then holds L
+    const bool want_factor = (A_r == nullptr || getenv("FINROM_DEBUG_RETURN_FACTOR") != nullptr) &&
+                             getenv("FINROM_NO_FUSED_CHOL") == nullptr;   // debug: A_r output then holds L
+    const int factor = (want_factor && d.NB <= 6) ? 1 : 0;            // in-register, inside the projection kernel
     if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, factor, info ? info + s0 : nullptr, st))) return rc;
+    int factored = factor;
+    if (want_factor && d.NB > 6) {                                     // wider bases: blocked MFMA Cholesky kernel
+      if ((rc = launch_rom_chol_blocked(d, (double*)h->Ar.p, Sc, info ? info + s0 : nullptr, st))) return rc;
+      factored = 1;
+    }
     if ((rc = launch_rom_solve(d, (const double*)h->Ar.p, (const double*)h->Br.p, Sc, w_r ? w_r + s0 * d.r : nullptr,
                                qoi_r ? qoi_r + s0 * d.n_obs : nullptr, A_r ? A_r + s0 * (int64_t)d.r * d.r : nullptr,
-                               B_r ? B_r + s0 * d.r : nullptr, info ? info + s0 : nullptr, factor, st))) return rc;
+                               B_r ? B_r + s0 * d.r : nullptr, info ? info + s0 : nullptr, factored, st))) return rc;
   }
   return 0;
 }

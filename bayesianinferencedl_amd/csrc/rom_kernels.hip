@@ -149,6 +149,120 @@ __device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, i
   return bad;
 }
 
+// ---------------------------------------------------------------------------------------
+// Blocked Cholesky for bases that need more than one projection wave (96 < r <= 208): one wave per sample,
+// in place on the packed A_r the projection kernel wrote.  Left-looking by block rows: the block row kb
+// (<= 13 tiles, in registers) first receives the updates -U(kp,kb)^T U(kp,tj) of all previous block rows
+// (tiles streamed back from memory, 4 MFMAs per tile), then is factored exactly like in chol_tiles and
+// written back as rows of U (= columns of L in the packed layout the substitution kernel reads).
+// ---------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(64) void rom_chol_blocked_kernel(RomDev p, double* __restrict__ Arp, int64_t S,
+                                                              int* __restrict__ info) {
+  const int lane = threadIdx.x, q = lane >> 4, c = lane & 15;
+  const int64_t s = blockIdx.x;
+  constexpr int R = 16 * NB;
+  double* A = Arp + s * (int64_t)(R * (R + 1) / 2);
+  auto at = [&](int row, int col) -> double& { return A[row * R - (row * (row - 1)) / 2 + col - row]; };   // row <= col
+  int bad = 0;
+#pragma unroll 1
+  for (int kb = 0; kb < NB; ++kb) {
+    d4 rowt[NB];
+#pragma unroll
+    for (int tj = 0; tj < NB; ++tj)
+      if (tj >= kb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int rr = 16 * kb + q + 4 * g, cc = 16 * tj + c;
+          double v = (cc >= rr) ? at(rr, cc) : at(cc, rr);          // the diagonal tile is mirrored from its upper half
+          if (rr == cc && rr >= p.r) v = 1.0;                        // padding rows: unit diagonal
+          rowt[tj][g] = v;
+        }
+      }
+#pragma unroll 1
+    for (int kp = 0; kp < kb; ++kp) {
+      double neg[4], ut[NB][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) neg[g] = -at(16 * kp + q + 4 * g, 16 * kb + c);
+#pragma unroll
+      for (int tj = 0; tj < NB; ++tj)
+        if (tj >= kb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) ut[tj][g] = at(16 * kp + q + 4 * g, 16 * tj + c);
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj)
+          if (tj >= kb)
+            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(rowt[tj]) : "v"(neg[g]), "v"(ut[tj][g]));
+#pragma unroll
+        for (int tj = 0; tj < NB; ++tj) {          // drain: same-accumulator MFMAs follow in the next k-step
+          if (tj == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(rowt[tj]));
+          else asm volatile("" : "+v"(rowt[tj]));
+        }
+      }
+    }
+    // factor the block row in registers (right-looking inside the 16 x 16(NB-kb) strip)
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int qs = st & 3, gs = st >> 2;
+      double dtile[4];
+#pragma unroll
+      for (int tj = 0; tj < NB; ++tj)
+        if (tj == kb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) dtile[g] = rowt[tj][g];
+        }
+      const double piv = __shfl(dtile[gs], qs * 16 + st);
+      bad |= !(piv > 0.0);
+      double rinv = __builtin_amdgcn_rsq(piv);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+      const double sc = (q == qs) ? rinv : 1.0;
+      double m[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double v = __shfl(dtile[gs] * sc, qs * 16 + ((q + 4 * g) & 15));
+        m[g] = (q + 4 * g > st) ? v : 0.0;
+      }
+#pragma unroll
+      for (int tj = 0; tj < NB; ++tj)
+        if (tj >= kb) {
+          rowt[tj][gs] *= sc;
+          const double rv = __shfl(rowt[tj][gs], qs * 16 + c);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rowt[tj][g] = fma(-m[g], rv, rowt[tj][g]);
+        }
+    }
+#pragma unroll
+    for (int tj = 0; tj < NB; ++tj)
+      if (tj >= kb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int rr = 16 * kb + q + 4 * g, cc = 16 * tj + c;
+          if (cc >= rr) at(rr, cc) = rowt[tj][g];
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next block rows read these tiles back
+    __syncthreads();
+  }
+  if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
+}
+
+int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_ROM_SOLVE, st);
+  switch (p.NB) {
+#define FR_CB(N) case N: hipLaunchKernelGGL(rom_chol_blocked_kernel<N>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, S, info); break;
+    FR_CB(7) FR_CB(8) FR_CB(9) FR_CB(10) FR_CB(11) FR_CB(12) FR_CB(13)
+#undef FR_CB
+    default: set_error("rom_chol_blocked: unsupported basis size"); return FINROM_ERR_UNSUPPORTED;
+  }
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int NB, int NW, int W>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
@@ -457,7 +571,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
                              block, 0, st, p, theta, S, Ar, Br, factor, info); break;
   switch (p.NB) {
     FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(5, 1) FR_CASE(6, 1)
-    FR_CASE(7, 2) FR_CASE(8, 2) FR_CASE(9, 2)
+    FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
     FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 4)
     default:
       set_error("rom_proj: basis size " + std::to_string(p.r) + " > 208 not supported");
@@ -719,9 +833,11 @@ int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_
   const size_t lds = ((p.solve_in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 2 * (size_t)p.rp) * sizeof(double);
   const int nset = (p.rp + 63) / 64;
 #define FR_SOLVE(L, N, F) return launch_solve_t<L, N, F>(p, lds, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info, st)
-  if (factored) {                       // only offered for rp <= 96 (one-wave projection)
+  if (factored) {
+    if (!p.solve_in_lds) FR_SOLVE(false, 4, true);
     if (nset == 1) FR_SOLVE(true, 1, true);
-    FR_SOLVE(true, 2, true);
+    if (nset == 2) FR_SOLVE(true, 2, true);
+    FR_SOLVE(true, 3, true);
   }
   if (p.solve_in_lds) {
     if (nset == 1) FR_SOLVE(true, 1, false);
