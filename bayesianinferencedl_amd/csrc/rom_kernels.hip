@@ -181,21 +181,17 @@ __global__ __launch_bounds__(64) void rom_chol_blocked_kernel(RomDev p, double* 
       }
 #pragma unroll 1
     for (int kp = 0; kp < kb; ++kp) {
-      double neg[4], ut[NB][4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) neg[g] = -at(16 * kp + q + 4 * g, 16 * kb + c);
+      for (int g = 0; g < 4; ++g) {       // operands of one k-step at a time: keeps the kernel free of AGPR spills
+        const double neg = -at(16 * kp + q + 4 * g, 16 * kb + c);
+        double ut[NB];
 #pragma unroll
-      for (int tj = 0; tj < NB; ++tj)
-        if (tj >= kb) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) ut[tj][g] = at(16 * kp + q + 4 * g, 16 * tj + c);
-        }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
+        for (int tj = 0; tj < NB; ++tj)
+          if (tj >= kb) ut[tj] = at(16 * kp + q + 4 * g, 16 * tj + c);
 #pragma unroll
         for (int tj = 0; tj < NB; ++tj)
           if (tj >= kb)
-            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(rowt[tj]) : "v"(neg[g]), "v"(ut[tj][g]));
+            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(rowt[tj]) : "v"(neg), "v"(ut[tj]));
 #pragma unroll
         for (int tj = 0; tj < NB; ++tj) {          // drain: same-accumulator MFMAs follow in the next k-step
           if (tj == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(rowt[tj]));
@@ -203,10 +199,13 @@ __global__ __launch_bounds__(64) void rom_chol_blocked_kernel(RomDev p, double* 
         }
       }
     }
-    // factor the block row in registers (right-looking inside the 16 x 16(NB-kb) strip)
+    // factor the block row in registers (right-looking inside the 16 x 16(NB-kb) strip); the register index
+    // gs of the pivot row is unrolled, its lane group qs is a run-time loop (4 code copies instead of 16)
 #pragma unroll
-    for (int st = 0; st < 16; ++st) {
-      const int qs = st & 3, gs = st >> 2;
+    for (int gs = 0; gs < 4; ++gs)
+#pragma unroll 1
+    for (int qs = 0; qs < 4; ++qs) {
+      const int st = 4 * gs + qs;
       double dtile[4];
 #pragma unroll
       for (int tj = 0; tj < NB; ++tj)
