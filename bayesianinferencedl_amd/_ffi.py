@@ -21,7 +21,7 @@ class FinromError(RuntimeError):
 class FomDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("nnzL", C.c_int32), ("xdim", C.c_int32), ("n_obs", C.c_int32),
                 ("nasm", C.c_int32), ("n_alist", C.c_int32), ("cache_slots", C.c_int32),
-                ("nops_fwd", C.c_int32), ("nops_bwd", C.c_int32),
+                ("fwd_chunk", C.c_int32), ("nops_fwd", C.c_int32), ("nops_bwd", C.c_int32),
                 ("a_list", c_i32p), ("asm_c0", c_f64p), ("asm_ptr", c_i32p), ("asm_idx", c_i32p),
                 ("asm_w", c_f64p), ("rhs", c_f64p),
                 ("fwd_kind", c_i32p), ("fwd_a", c_i32p), ("fwd_b", c_i32p), ("fwd_d", c_i32p),
@@ -101,7 +101,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 1:
+        if L.finrom_version() != 2:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -26,7 +26,7 @@ int Scratch::reserve(size_t bytes) {
 void Scratch::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 // ---- profiling -------------------------------------------------------------------------
-static const char* kSlotNames[K_NUM] = {"pack", "fom_chol_solve", "unpack_w", "rom_proj_mfma",
+static const char* kSlotNames[K_NUM] = {"pack", "fom_assemble", "fom_chol_solve", "unpack_w", "rom_proj_mfma",
                                         "rom_reduced_solve", "subfin_avg", "sampler_gemm_exp", "misc"};
 struct Pending { int slot; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;
@@ -161,14 +161,15 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   *out = nullptr;
   const int n = a->n, nnzL = a->nnzL;
   if (n <= 0 || nnzL < n || a->xdim <= 0 || a->n_obs < 0 || a->nasm < 0 || a->n_alist < 0 || a->cache_slots < 1 ||
-      a->cache_slots > 64 || a->nops_fwd < 2 * VM_CHUNK || a->nops_bwd < 2 * VM_CHUNK ||
-      a->nops_fwd % (2 * VM_CHUNK) || a->nops_bwd % (2 * VM_CHUNK)) {
+      a->cache_slots > 126 || (a->fwd_chunk != 8 && a->fwd_chunk != 16) || a->nops_fwd < 2 * a->fwd_chunk ||
+      a->nops_bwd < 2 * VM_CHUNK || a->nops_fwd % (2 * a->fwd_chunk) || a->nops_bwd % (2 * VM_CHUNK)) {
     set_error("fom_create: inconsistent sizes"); return FINROM_ERR_ARG;
   }
   // validate every index the kernels will dereference (a bad index would fault the GPU) and
   // the prefetch rule of the op streams
   auto bad = [&](const char* what) { set_error(std::string("fom_create: invalid ") + what); return FINROM_ERR_ARG; };
   const int gsize = nnzL + 2 * n;
+  if ((int64_t)(nnzL + 3 * (int64_t)n) * 512 >= (int64_t)1 << 31) { set_error("fom_create: value vector too long for 32-bit buffer offsets"); return FINROM_ERR_UNSUPPORTED; }
   for (int t = 0; t < a->n_alist; ++t) if (a->a_list[t] < 0 || a->a_list[t] >= nnzL) return bad("a_list");
   if (a->asm_ptr[0] != 0 || a->asm_ptr[nnzL] != a->nasm) return bad("asm_ptr");
   for (int e = 0; e < nnzL; ++e) if (a->asm_ptr[e + 1] < a->asm_ptr[e]) return bad("asm_ptr");
@@ -177,7 +178,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
     std::vector<int> stored(gsize, -10);
     auto need = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 2 <= c; };
     for (int t = 0; t < a->nops_fwd; ++t) {
-      const int k = a->fwd_kind[t], A = a->fwd_a[t], B = a->fwd_b[t], D = a->fwd_d[t], c = t / VM_CHUNK;
+      const int k = a->fwd_kind[t], A = a->fwd_a[t], B = a->fwd_b[t], D = a->fwd_d[t], c = t / a->fwd_chunk;
       switch (k) {
         case 0: if ((A >= 0 && !need(A, c)) || A < -1 || B < 0 || B >= a->cache_slots + 2) return bad("forward FMA op"); break;
         case 3: case 4: if (!need(A, c)) return bad("forward LDX/FMAX op"); break;
@@ -187,7 +188,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
         case 8: if (D < nnzL + n || D >= gsize) return bad("forward FINY op"); stored[D] = c; break;
         default: return bad("forward op kind");
       }
-      if (t >= a->nops_fwd - 2 * VM_CHUNK && (k != 0 || B != a->cache_slots + 1)) return bad("forward stream tail (must be padding)");
+      if (t >= a->nops_fwd - 2 * a->fwd_chunk && (k != 0 || B != a->cache_slots + 1)) return bad("forward stream tail (must be padding)");
     }
     std::fill(stored.begin(), stored.end(), -10);
     auto need1 = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 1 <= c; };   // backward: fetched per chunk
@@ -217,22 +218,41 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   FomDev& d = h->d;
   d.n = n; d.nnzL = nnzL; d.xdim = a->xdim; d.n_obs = a->n_obs; d.n_alist = a->n_alist; d.cache_slots = a->cache_slots;
   d.gsize = gsize;
-  d.nchunks_fwd = a->nops_fwd / VM_CHUNK - 2; d.nchunks_bwd = a->nops_bwd / VM_CHUNK - 2;
-  d.debug_phases = 7;
+  d.fwd_chunk = a->fwd_chunk;
+  d.nchunks_fwd = a->nops_fwd / a->fwd_chunk - 2; d.nchunks_bwd = a->nops_bwd / VM_CHUNK - 2;
+  d.debug_phases = 7; d.trace = nullptr;
   d.has_grad = 0; d.nchunks_res = 0;
   if (const char* ph = getenv("FINROM_FOM_PHASES")) d.debug_phases = atoi(ph);
   std::vector<int> fkb(a->nops_fwd), bkb(a->nops_bwd);
-  for (int t = 0; t < a->nops_fwd; ++t) fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8);
+  // device encoding of the forward stream: load offsets in bytes (padding ops re-read element 0), the common
+  // multiply-add carries the LDS byte offset of its row-cache slot, every other op kind | (b+1) << 8, and one bit
+  // mask per chunk flags the slots that are NOT plain multiply-adds
+  std::vector<int> fa2(a->nops_fwd), fmask(a->nops_fwd / a->fwd_chunk, 0);
+  for (int t = 0; t < a->nops_fwd; ++t) {
+    fa2[t] = std::max(a->fwd_a[t], 0) * 512;
+    if (a->fwd_kind[t] == 0) fkb[t] = a->fwd_b[t] * 512;
+    else { fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8); fmask[t / a->fwd_chunk] |= 1 << (t % a->fwd_chunk); }
+  }
   for (int t = 0; t < a->nops_bwd; ++t) bkb[t] = a->bwd_kind[t] | ((a->bwd_b[t] + 1) << 8);
   int rc = 0;
   const int nobsnz = a->n_obs > 0 ? a->obs_ptr[a->n_obs] : 0;
-  if (!rc) rc = up(h->owned, &d.a_list, a->a_list, a->n_alist);
-  if (!rc) rc = up(h->owned, &d.asm_c0, a->asm_c0, nnzL);
-  if (!rc) rc = up(h->owned, &d.asm_ptr, a->asm_ptr, nnzL + 1);
+  // assembly records: {entry, idx0..3, first/last of the remaining terms, 0} and {c0, w0..3}; unused slots
+  // multiply parameter 0 by a zero weight
+  std::vector<int> reci((size_t)a->n_alist * 8, 0);
+  std::vector<double> recd((size_t)a->n_alist * 5, 0.0);
+  for (int t = 0; t < a->n_alist; ++t) {
+    const int e = a->a_list[t], t0 = a->asm_ptr[e], t1 = a->asm_ptr[e + 1];
+    reci[t * 8 + 0] = e; recd[t * 5 + 0] = a->asm_c0[e];
+    for (int k = 0; k < 4 && t0 + k < t1; ++k) { reci[t * 8 + 1 + k] = a->asm_idx[t0 + k]; recd[t * 5 + 1 + k] = a->asm_w[t0 + k]; }
+    reci[t * 8 + 5] = std::min(t0 + 4, t1); reci[t * 8 + 6] = t1;
+  }
+  if (!rc) rc = up(h->owned, &d.asm_rec_i, reci.data(), reci.size());
+  if (!rc) rc = up(h->owned, &d.asm_rec_d, recd.data(), recd.size());
   if (!rc) rc = up(h->owned, &d.asm_idx, a->asm_idx, a->nasm);
   if (!rc) rc = up(h->owned, &d.asm_w, a->asm_w, a->nasm);
   if (!rc) rc = up(h->owned, &d.rhs, a->rhs, n);
-  if (!rc) rc = up(h->owned, &d.f_a, a->fwd_a, a->nops_fwd);
+  if (!rc) rc = up(h->owned, &d.f_a, fa2.data(), fa2.size());
+  if (!rc) rc = up(h->owned, &d.f_mask, fmask.data(), fmask.size());
   if (!rc) rc = up(h->owned, &d.f_kb, fkb.data(), fkb.size());
   if (!rc) rc = up(h->owned, &d.f_d, a->fwd_d, a->nops_fwd);
   if (!rc) rc = up(h->owned, &d.b_a, a->bwd_a, a->nops_bwd);
@@ -254,26 +274,39 @@ void finrom_fom_destroy(finrom_fom_t h) {
   delete h;
 }
 
-int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, void* stream) {
-  if (!h || S < 0 || (S > 0 && (!x || (!qoi && h->d.n_obs > 0)))) { set_error("fom_solve: bad argument"); return FINROM_ERR_ARG; }
-  hipStream_t st = (hipStream_t)stream;
-  const FomDev& d = h->d;
+// stages: 1 = pack + assembly, 2 = interpreter (+ unpack of w), 3 = both.  finrom_solve_pairs runs stage 1, then
+// launches the ROM half, then stage 2 (only possible when the batch fits one workspace chunk).
+static int64_t fom_chunk_samples(const FomDev& d) {
   // bound the per-call workspace (L values dominate: nnzL * 8 B per sample)
   const size_t per_sample = ((size_t)d.gsize + d.xdim) * sizeof(double);
-  int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
-  chunk = std::max<int64_t>(64, chunk / 64 * 64);
+  const int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
+  return std::max<int64_t>(64, chunk / 64 * 64);
+}
+static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, hipStream_t st,
+                            int stages) {
+  const FomDev& d = h->d;
+  const int64_t chunk = fom_chunk_samples(d);
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t Sc = std::min(chunk, S - s0);
     const int64_t nblk = (Sc + 63) / 64;
     int rc;
-    if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
-    if ((rc = h->Gw.reserve((size_t)nblk * d.gsize * 64 * sizeof(double)))) return rc;
-    if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
-    if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Gw.p,
-                         qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
-    if (w && (rc = launch_unpack_w(d, (const double*)h->Gw.p, Sc, w + s0 * d.n, st))) return rc;
+    if (stages & 1) {
+      if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+      if ((rc = h->Gw.reserve((size_t)nblk * d.gsize * 64 * sizeof(double)))) return rc;
+      if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
+      if ((rc = launch_fom_assemble(d, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
+    }
+    if (stages & 2) {
+      if ((rc = launch_fom(d, nblk, Sc, (double*)h->Gw.p, qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
+      if (w && (rc = launch_unpack_w(d, (const double*)h->Gw.p, Sc, w + s0 * d.n, st))) return rc;
+    }
   }
   return 0;
+}
+
+int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, void* stream) {
+  if (!h || S < 0 || (S > 0 && (!x || (!qoi && h->d.n_obs > 0)))) { set_error("fom_solve: bad argument"); return FINROM_ERR_ARG; }
+  return fom_solve_stages(h, x, S, qoi, w, info, (hipStream_t)stream, 3);
 }
 
 int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* a) {
@@ -340,7 +373,8 @@ int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int
     double* q = qoi ? qoi + s0 * d.n_obs : nullptr;
     if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
     if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
-    if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Gw.p, q, info ? info + s0 : nullptr, st))) return rc;
+    if ((rc = launch_fom_assemble(d, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
+    if ((rc = launch_fom(d, nblk, Sc, (double*)h->Gw.p, q, info ? info + s0 : nullptr, st))) return rc;
     if ((rc = launch_fom_adjoint(d, nblk, Sc, (double*)h->Gw.p, q, data + (data_per_sample ? s0 * d.n_obs : 0),
                                  data_per_sample ? d.n_obs : 0, (double*)h->gradT.p, J + s0, st))) return rc;
     if ((rc = launch_unpack((const double*)h->gradT.p, Sc, d.xdim, d.xdim, 0, nullptr, grad + s0 * d.xdim, st))) return rc;
@@ -373,7 +407,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   RomDev& d = h->d;
   d.n = a->n; d.r = r; d.rp = rp; d.NB = NB; d.P = a->P; d.n_obs = a->n_obs;
   d.solve_in_lds = rp <= 176 ? 1 : 0;
-  d.clock_probe = getenv("FINROM_CLOCK_PROBE") != nullptr;
+  d.clock_probe = getenv("FINROM_CLOCK_PROBE") != nullptr; d.trace = nullptr;
   d.n_phases = 0;
   std::vector<double> tv; std::vector<int> pidx;
   auto push_slot = [&](std::vector<double>& T, std::vector<int>& Pi, const std::vector<int>& rows4, int t) {
@@ -562,6 +596,21 @@ int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n, const double* k, 
   return launch_subfin_avg(Sop, P, n, k, S, theta, (hipStream_t)stream);
 }
 
+// FINROM_TRACE=<prefix>: every finrom_solve_pairs call records, per workgroup of the FOM interpreter and of the
+// projection kernel, {start, end, HW_ID, XCC_ID} and rewrites <prefix>.fom.bin / <prefix>.proj.bin (int64 x 4 per
+// workgroup) after a device synchronisation.  Diagnostic for the co-residency of the two halves.
+static long long* g_trace_buf[2] = {nullptr, nullptr};
+static constexpr size_t kTraceWg = 1u << 18;
+static const char* trace_prefix() { static const char* p = getenv("FINROM_TRACE"); return p; }
+static int trace_dump(const char* kind, long long* dbuf, size_t nwg) {
+  std::vector<long long> h(nwg * 4);
+  FR_HIP(hipDeviceSynchronize());
+  FR_HIP(hipMemcpy(h.data(), dbuf, nwg * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+  const std::string path = std::string(trace_prefix()) + "." + kind + ".bin";
+  if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }
+  return 0;
+}
+
 int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, const double* x, int64_t S,
                        double* qoi, double* qoi_r, double* err, double* w, double* w_r, double* theta,
                        int32_t* info, void* stream) {
@@ -583,6 +632,16 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   }
   const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr;   // serial mode: per-kernel profiling
   hipStream_t side = overlap ? rom->side : st;
+  const bool tracing = trace_prefix() != nullptr;
+  if (tracing) {
+    for (int i = 0; i < 2; ++i)
+      if (!g_trace_buf[i]) FR_HIP(hipMalloc((void**)&g_trace_buf[i], kTraceWg * 4 * sizeof(long long)));
+    FR_HIP(hipMemset(g_trace_buf[0], 0, kTraceWg * 4 * sizeof(long long)));
+    FR_HIP(hipMemset(g_trace_buf[1], 0, kTraceWg * 4 * sizeof(long long)));
+    FR_HIP(hipDeviceSynchronize());
+    fom->d.trace = (size_t)((S + 63) / 64) <= kTraceWg ? g_trace_buf[0] : nullptr;
+    rom->d.trace = (size_t)S <= kTraceWg ? g_trace_buf[1] : nullptr;
+  }
   // fork: everything already queued on the caller's stream (inputs, zeroed info) precedes both halves
   if (overlap) {
     FR_HIP(hipEventRecord(rom->ev_fork, st));
@@ -590,14 +649,27 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   }
   // ROM half first, on a high-priority stream: its 4-wave, 160-VGPR workgroups need large contiguous
   // register ranges, so they claim their slots before the small FOM waves fill the remaining ones
+  // The FOM's short bandwidth-bound pre-pass (pack + assembly) runs first, alone; beside the projection kernel it
+  // would crawl and hold back the interpreter, whose waves then start late.
+  const bool split = S <= fom_chunk_samples(fom->d);
+  if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return rc;
+  if (overlap && split) {                 // the ROM half starts after the pre-pass
+    FR_HIP(hipEventRecord(rom->ev_fork, st));
+    FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
+  }
   if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, side))) return rc;
   if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return rc;
-  if ((rc = finrom_fom_solve(fom, x, S, qoi, w, info, st))) return rc;
+  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, split ? 2 : 3))) return rc;
   if (overlap) {
     FR_HIP(hipEventRecord(rom->ev_join, side));
     FR_HIP(hipStreamWaitEvent(st, rom->ev_join, 0));
   }
   if (err && (rc = launch_sub(qoi, qoi_r, S * (int64_t)fom->d.n_obs, err, st))) return rc;
+  if (tracing) {
+    if (fom->d.trace) trace_dump("fom", g_trace_buf[0], (size_t)((S + 63) / 64));
+    if (rom->d.trace) trace_dump("proj", g_trace_buf[1], (size_t)S);
+    fom->d.trace = nullptr; rom->d.trace = nullptr;
+  }
   return 0;
 }
 

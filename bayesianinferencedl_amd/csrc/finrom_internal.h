@@ -23,7 +23,8 @@ int hip_fail(hipError_t e, const char* what);
 // ---- per-kernel HIP-event timing (finrom_profile_*) ------------------------------------
 enum KernelSlot {
   K_PACK = 0,      // row-major [S x d] -> sample-blocked [S/64][d][64]
-  K_FOM,           // affine assembly + sparse Cholesky + two triangular solves + QoI
+  K_FOM_ASM,       // affine assembly of the entries of A (pre-pass of the interpreter)
+  K_FOM,           // sparse Cholesky + two triangular solves + QoI (schedule interpreter)
   K_UNPACK_W,      // blocked w -> row-major, original dof order
   K_ROM_PROJ,      // psi build + psi^T psi (fp64 MFMA) + psi^T F
   K_ROM_SOLVE,     // dense Cholesky solve of the reduced system + QoI
@@ -55,16 +56,31 @@ struct Scratch {
   void release();
 };
 
+// FINROM_TRACE diagnostic: workgroup residency trace (start/end on the 100 MHz real-time counter + where it ran)
+__device__ __forceinline__ void trace_begin(long long* tr, int64_t wg) {
+  if (tr != nullptr && threadIdx.x == 0) {
+    tr[wg * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    tr[wg * 4 + 2] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_REG_HW_ID
+    tr[wg * 4 + 3] = __builtin_amdgcn_s_getreg(20 | (31 << 11));     // HW_REG_XCC_ID
+  }
+}
+__device__ __forceinline__ void trace_end(long long* tr, int64_t wg) {
+  if (tr != nullptr && threadIdx.x == 0) tr[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+}
+
 // ---- FOM ------------------------------------------------------------------------------
 constexpr int VM_CHUNK = 8;        // ops whose global operands are fetched together, one chunk ahead
 struct FomDev {
+  long long* trace;   // FINROM_TRACE: per-workgroup {start, end (10 ns ticks), HW_ID, XCC_ID}; nullptr = off
   int debug_phases;   // bit 0 factor+forward, 1 backward, 2 QoI (FINROM_FOM_PHASES, timing experiments only; default 7)
-  int n, nnzL, xdim, n_obs, n_alist, cache_slots;
+  int n, nnzL, xdim, n_obs, n_alist, cache_slots, fwd_chunk;
   int gsize;                         // values per sample: nnzL + 2n  (L | 1/L_ii | y,w)
   int nchunks_fwd, nchunks_bwd;      // executed chunks (the streams carry 2 more chunks of NOP padding)
-  const int* a_list; const double* asm_c0; const int* asm_ptr; const int* asm_idx; const double* asm_w;
+  const int* asm_rec_i; const double* asm_rec_d;       // [n_alist][8] / [n_alist][5] fixed-size assembly records
+  const int* asm_idx; const double* asm_w;            // terms beyond the first four of an entry
   const double* rhs;
-  const int* f_a; const int* f_kb; const int* f_d;     // forward stream: load index, kind | (b+1) << 8, d
+  const int* f_a; const int* f_kb; const int* f_d;     // forward stream: load byte offset, LDS byte offset (FMA) or kind | (b+1) << 8, d
+  const int* f_mask;                                   // per chunk: bit u set = slot u is not a plain multiply-add
   const int* b_a; const int* b_kb; const int* b_d;     // backward stream
   const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
   // adjoint gradient (finrom_fom_set_gradient); the value vector then has a 4th region v at nnzL + 2n
@@ -77,7 +93,8 @@ int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, con
                        int64_t data_stride, double* gradT, double* J, hipStream_t st);
 int launch_unpack(const double* srcT, int64_t S, int d, int64_t blk_stride, int off, const int* perm, double* dst, hipStream_t st);
 int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st);
-int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st);
+int launch_fom_assemble(const FomDev& p, const double* xT, int64_t nblk, double* Gw, hipStream_t st);
+int launch_fom(const FomDev& p, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st);
 int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st);
 
 // ---- ROM ------------------------------------------------------------------------------
@@ -85,6 +102,7 @@ constexpr int ROM_MAX_PHASES = 8;
 struct RomDev {
   int n, r, rp, NB, P, n_obs;           // rp = 16*NB padded basis size
   int solve_in_lds;                     // packed factor fits in LDS (rp <= 176)
+  long long* trace;                     // FINROM_TRACE (see FomDev::trace)
   int clock_probe;                      // FINROM_CLOCK_PROBE: a few workgroups print their shader clock (diagnostic)
   // psi tables, rows grouped 4 per k-step and sorted by term count into phases of constant NT
   int n_phases;

@@ -50,29 +50,45 @@ int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
-// assembly pre-pass: G[e] = A_e(x) for every entry of L that carries a value of A
-// (fom :160-161 / rom :154-163).  Embarrassingly parallel, lane = sample, coalesced stores.
+// assembly pre-pass: G[e] = A_e(x) = c0_e + sum_t w_t x[idx_t] for every entry of L that carries a value of A
+// (fom :160-161 / rom :154-163).  lane = sample, coalesced 512-B stores.  The per-entry table is a fixed-size
+// record (rec_i: entry, 4 parameter indices, range of the remaining terms; rec_d: c0, 4 weights) fetched with
+// two independent scalar loads, so the records of the next entries are in flight while this one is applied.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void fom_assemble_kernel(FomDev p, const int* __restrict__ a_list,
-                                                           const double* __restrict__ asm_c0, const int* __restrict__ asm_ptr,
+__global__ __launch_bounds__(256) void fom_assemble_kernel(FomDev p, const int* __restrict__ rec_i, const double* __restrict__ rec_d,
                                                            const int* __restrict__ asm_idx, const double* __restrict__ asm_w,
                                                            const double* __restrict__ xT, double* __restrict__ Gw) {
   const int lane = threadIdx.x & 63;
-  const int part = (threadIdx.x >> 6) + 4 * blockIdx.y, nparts = 4 * gridDim.y;
+  // the wave index is uniform, but only readfirstlane tells the compiler so (scalar record loads)
+  const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + 4 * blockIdx.y, nparts = 4 * gridDim.y;
   const int64_t blk = blockIdx.x;
   const double* xb = xT + blk * (int64_t)p.xdim * 64 + lane;
   double* G = Gw + blk * (int64_t)p.gsize * 64 + lane;
-  for (int t = part; t < p.n_alist; t += nparts) {
-    const int e = a_list[t];
-    const int t0 = asm_ptr[e], t1 = asm_ptr[e + 1];
-    double xv[4];
+  constexpr int U = 4;                                    // entries in flight per wave
+  for (int t0 = part * U; t0 < p.n_alist; t0 += nparts * U) {
+    int ri[U][8];
+    double rd[U][5];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xv[u] = xb[(int64_t)asm_idx[(t0 + u < t1) ? t0 + u : (t1 > t0 ? t1 - 1 : 0)] * 64];
-    double acc = asm_c0[e];
+    for (int u = 0; u < U; ++u) {
+      const int t = (t0 + u < p.n_alist) ? t0 + u : p.n_alist - 1;     // tail: recompute the last entry
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = fma((t0 + u < t1) ? asm_w[t0 + u] : 0.0, xv[u], acc);
-    for (int q = t0 + 4; q < t1; ++q) acc = fma(asm_w[q], xb[(int64_t)asm_idx[q] * 64], acc);
-    G[(int64_t)e * 64] = acc;
+      for (int k = 0; k < 8; ++k) ri[u][k] = rec_i[t * 8 + k];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) rd[u][k] = rec_d[t * 5 + k];
+    }
+    double xv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xv[u][k] = xb[(int64_t)ri[u][1 + k] * 64];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double acc = rd[u][0];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc = fma(rd[u][1 + k], xv[u][k], acc);
+      for (int q = ri[u][5]; q < ri[u][6]; ++q) acc = fma(asm_w[q], xb[(int64_t)asm_idx[q] * 64], acc);   // entries with > 4 terms
+      G[(int64_t)ri[u][0] * 64] = acc;
+    }
   }
 }
 
@@ -88,64 +104,85 @@ enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
 // prove that the stores to G never clobber them and fetch the descriptors with SCALAR loads
 // (s_load_dwordx8); through the by-value struct they become vector loads + v_readfirstlane whose
 // s_waitcnt vmcnt(0) drains the operand prefetch on every op.
+template <int FCH>      // FCH = ops per prefetch chunk of the forward stream
 __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __restrict__ fA, const int* __restrict__ fKB,
-                                                    const int* __restrict__ fD, const int* __restrict__ bA,
+                                                    const int* __restrict__ fD, const int* __restrict__ fM, const int* __restrict__ bA,
                                                     const int* __restrict__ bKB, const int* __restrict__ bD,
                                                     const double* __restrict__ rhs, const int* __restrict__ obs_ptr,
                                                     const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
                                                     double* __restrict__ Gw, int64_t S,
                                                     double* __restrict__ qoi, int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double rowc[];   // [cache_slots + 2][64] row cache + 2 constants
-  const int lane = threadIdx.x;
+  // LDS: [cache_slots] row cache | NEG1 | ZERO | INV | XREG | BAD, each 64 lanes x 8 B.  The interpreter state that
+  // only the rare ops touch (1/L_ii of the current row, the LDX operand, the failure flag) lives in LDS, not in
+  // registers: loop-carried registers that the common multiply-add does not modify cost a register move per
+  // unrolled op, and every VALU instruction of this kernel competes with the projection kernel's MFMAs.
+  extern __shared__ __attribute__((aligned(16))) double rowc[];
+  const unsigned lane = threadIdx.x;
   const int64_t blk = blockIdx.x;
-  double* G = Gw + blk * (int64_t)p.gsize * 64 + lane;
+  double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;     // wave-uniform base: scalar address + lane offset
+  double* G = Gs + lane;
   double* rc = rowc + lane;
-  rc[p.cache_slots * 64] = -1.0;          // NEG1 slot: "acc = A_e" is an FMA against it
-  rc[(p.cache_slots + 1) * 64] = 0.0;     // ZERO slot: padding ops
-  int bad = 0;
-  double acc = 0.0, inv = 0.0, xreg = 0.0;
+  trace_begin(p.trace, blk);
+  const int S_NEG1 = p.cache_slots, S_ZERO = p.cache_slots + 1, S_INV = p.cache_slots + 2, S_XREG = p.cache_slots + 3,
+            S_BAD = p.cache_slots + 4;
+  rc[S_NEG1 * 64] = -1.0;          // "acc = A_e" is an FMA against it
+  rc[S_ZERO * 64] = 0.0;           // padding ops
+  rc[S_INV * 64] = 0.0; rc[S_XREG * 64] = 0.0; rc[S_BAD * 64] = 0.0;
+  double acc = 0.0;
+  // operand fetches are buffer loads: descriptor + element offset in SGPRs, lane offset in one VGPR -- no
+  // per-load vector address arithmetic
+  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000);
+  const int lane8 = (int)lane * 8;
+  auto ldg = [&](int e) -> double {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(gres, lane8, e * 512, 0));
+  };
 
-  // (padding ops, a < 0, re-read element 0: a uniform branch per load to skip them measured slower)
+  auto ldgb = [&](int byte_off) -> double {      // forward stream: offsets are pre-scaled on the host
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(gres, lane8, byte_off, 0));
+  };
+  const char* rcb = reinterpret_cast<const char*>(rowc) + lane8;
+
 #define VM_LOAD1(buf, c)                                                      \
-  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
-    const int a_ = A[(c) * VM_CHUNK + u];                                     \
-    buf[u] = G[(int64_t)(a_ < 0 ? 0 : a_) * 64];                              \
-  }
+  _Pragma("unroll") for (int u = 0; u < FCH; ++u) buf[u] = ldgb(A[(c) * FCH + u]);
 
   // ---- forward: numeric factorisation A = L L^T fused with L y = F -------------------
+  // Instruction count per op matters: beside the projection kernel every instruction of this wave waits for a
+  // gap in the MFMA stream.  Plain multiply-add: bit test + branch, LDS address, ds_read, fma.
   if (p.debug_phases & 1) {
     const int* __restrict__ A = fA; const int* __restrict__ KB = fKB; const int* __restrict__ D = fD;
-    double bufA[VM_CHUNK], bufB[VM_CHUNK];
+    double bufA[FCH], bufB[FCH];
 #define VM_EXEC_F(buf, c)                                                     \
-  int kbv[VM_CHUNK], dv[VM_CHUNK];   /* descriptors of the whole chunk: two s_load_dwordx8 */ \
-  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = KB[(c) * VM_CHUNK + u]; dv[u] = D[(c) * VM_CHUNK + u]; } \
-  _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                      \
-    const int kb = kbv[u];                                                    \
-    const int kind = kb & 255, b = (kb >> 8) - 1;                             \
+  int kbv[FCH];            /* descriptors of the whole chunk: scalar loads */ \
+  _Pragma("unroll") for (int u = 0; u < FCH; ++u) kbv[u] = KB[(c) * FCH + u]; \
+  const int msk = fM[c];                                                      \
+  _Pragma("unroll") for (int u = 0; u < FCH; ++u) {                           \
     const double ld = buf[u];                                                 \
-    if (__builtin_expect(kind == F_FMA, 1)) {                                 \
-      acc = fma(-rc[b * 64], ld, acc);   /* also "acc = A_e" (NEG1 slot) and padding (ZERO slot) */ \
+    if (__builtin_expect(!(msk & (1 << u)), 1)) {                             \
+      acc = fma(-*reinterpret_cast<const double*>(rcb + kbv[u]), ld, acc);   /* also "acc = A_e" (NEG1) and padding (ZERO) */ \
     } else {                                                                  \
-      const int d = dv[u];                                                    \
+      const int kb = kbv[u];                                                  \
+      const int kind = kb & 255, b = (kb >> 8) - 1;                           \
+      const int d = D[(c) * FCH + u];                                         \
       switch (kind) {                                                         \
-        case F_LDX: xreg = ld; break;             /* row entry beyond the LDS cache */ \
-        case F_FMAX: acc = fma(-xreg, ld, acc); break;                        \
+        case F_LDX: rc[S_XREG * 64] = ld; break;   /* row entry beyond the LDS cache */ \
+        case F_FMAX: acc = fma(-rc[S_XREG * 64], ld, acc); break;             \
         case F_FINOFF: {                                                      \
           const double l = acc * ld;                                          \
-          G[(int64_t)d * 64] = l;                                             \
+          Gs[(int64_t)d * 64 + lane] = l;                                     \
           if (b >= 0) rc[b * 64] = l;                                         \
           acc = 0.0;                                                          \
         } break;                                                              \
         case F_FINDIAG: {                                                     \
-          bad |= !(acc > 0.0);                                                \
+          if (!(acc > 0.0)) rc[S_BAD * 64] = 1.0;                             \
           const double t = sqrt(acc);                                         \
-          inv = 1.0 / t;                                                      \
-          G[(int64_t)d * 64] = t;                                             \
-          G[(int64_t)(p.nnzL + b) * 64] = inv;                                \
+          const double inv = 1.0 / t;                                         \
+          Gs[(int64_t)d * 64 + lane] = t;                                     \
+          Gs[(int64_t)(p.nnzL + b) * 64 + lane] = inv;                        \
+          rc[S_INV * 64] = inv;                                               \
           acc = 0.0;                                                          \
         } break;                                                              \
         case F_YSET: acc = rhs[d]; break;                                     \
-        case F_FINY: G[(int64_t)d * 64] = acc * inv; acc = 0.0; break;        \
+        case F_FINY: Gs[(int64_t)d * 64 + lane] = acc * rc[S_INV * 64]; acc = 0.0; break; \
         default: break;                                                       \
       }                                                                       \
     }                                                                         \
@@ -159,6 +196,7 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
     }
 #undef VM_EXEC_F
   }
+  const int bad = rc[S_BAD * 64] != 0.0;
 
   // ---- backward: L^T w = y, w overwrites y ----------------------------------------------
   if (p.debug_phases & 2) {
@@ -174,8 +212,8 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
       for (int u = 0; u < VM_CHUNK; ++u) {
         const int a_ = A[c * VM_CHUNK + u];
         const int b_ = (kbv[u] >> 8) - 1;
-        a1[u] = G[(int64_t)(a_ < 0 ? 0 : a_) * 64];
-        b1[u] = G[(int64_t)(b_ < 0 ? 0 : b_) * 64];
+        a1[u] = ldg(a_ < 0 ? 0 : a_);
+        b1[u] = ldg(b_ < 0 ? 0 : b_);
       }
 #pragma unroll
       for (int u = 0; u < VM_CHUNK; ++u) {
@@ -211,18 +249,28 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   if (bad)
     for (int i = 0; i < p.n; ++i) G[(int64_t)(p.nnzL + p.n + i) * 64] = nanv;
   if (info != nullptr && s < S && bad) atomicOr(&info[s], 1);   // the ROM half may set bit 1 concurrently
+  trace_end(p.trace, blk);
 }
 
-int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info,
-               hipStream_t st) {
+int launch_fom_assemble(const FomDev& p, const double* xT, int64_t nblk, double* Gw, hipStream_t st) {
   if (nblk == 0) return 0;
-  ScopedKernelTimer t(K_FOM, st);
-  hipLaunchKernelGGL(fom_assemble_kernel, dim3((unsigned)nblk, 4), dim3(256), 0, st, p, p.a_list, p.asm_c0, p.asm_ptr, p.asm_idx,
+  ScopedKernelTimer t(K_FOM_ASM, st);
+  hipLaunchKernelGGL(fom_assemble_kernel, dim3((unsigned)nblk, 4), dim3(256), 0, st, p, p.asm_rec_i, p.asm_rec_d, p.asm_idx,
                      p.asm_w, xT, Gw);
   FR_HIP(hipGetLastError());
-  const size_t lds = (size_t)(p.cache_slots + 2) * 64 * sizeof(double);
-  hipLaunchKernelGGL(fom_vm_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.b_a, p.b_kb, p.b_d,
-                     p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, Gw, S, qoi, info);
+  return 0;
+}
+
+int launch_fom(const FomDev& p, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st) {
+  if (nblk == 0) return 0;
+  ScopedKernelTimer t(K_FOM, st);
+  const size_t lds = (size_t)(p.cache_slots + 5) * 64 * sizeof(double);
+  if (p.fwd_chunk == 16)
+    hipLaunchKernelGGL(fom_vm_kernel<16>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.b_a, p.b_kb,
+                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, Gw, S, qoi, info);
+  else
+    hipLaunchKernelGGL(fom_vm_kernel<8>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.b_a, p.b_kb,
+                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, Gw, S, qoi, info);
   FR_HIP(hipGetLastError());
   return 0;
 }

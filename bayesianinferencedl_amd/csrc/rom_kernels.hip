@@ -49,7 +49,7 @@ template <int NB, int NW, int W>
 __device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
   // Bases wider than 128 spill accumulators; spill code next to inline asm is not hazard-safe
   // (the compiler cannot see that the asm is an MFMA), so those sizes use the compiler-managed builtin.
-  constexpr bool kAsm = NB <= 8;
+  constexpr bool kAsm = NB <= 10 || NW >= 8;   // (NB, NW) whose accumulators fit architectural VGPRs without spills
   int idx = 0, mine = 0;
 #pragma unroll
   for (int ti = 0; ti < NB; ++ti)
@@ -126,12 +126,13 @@ __device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, i
     // trailing update: T(ti,tj) -= U(kb,ti)^T U(kb,tj)
     if (kb + 1 < NB) {
       // operands are copied out of the accumulator tuples into plain 64-bit registers first (a sub-register
-      // of a 256-bit inline-asm tuple is not guaranteed to be a legal, even-aligned MFMA source)
-      double neg[NB][4], pos[NB][4];
+      // of a 256-bit inline-asm tuple is not guaranteed to be a legal, even-aligned MFMA source); the minus sign
+      // of the update rides on the instruction's source-A negate modifier
+      double pos[NB][4];
 #pragma unroll
       for (int ti = kb + 1; ti < NB; ++ti)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { pos[ti][g] = acc[dg + (ti - kb)][g]; neg[ti][g] = -pos[ti][g]; }
+        for (int g = 0; g < 4; ++g) pos[ti][g] = acc[dg + (ti - kb)][g];
       // k-step g outermost: consecutive MFMAs hit different tiles; the drain between k-steps covers the
       // MFMA -> same-accumulator MFMA hazard that hipcc cannot pad around inline asm
 #pragma unroll
@@ -140,8 +141,8 @@ __device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, i
         for (int ti = kb + 1; ti < NB; ++ti)
 #pragma unroll
           for (int tj = ti; tj < NB; ++tj)
-            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0"
-                         : "+v"(acc[tile_index<NB>(ti, tj)]) : "v"(neg[ti][g]), "v"(pos[tj][g]));
+            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]"
+                         : "+v"(acc[tile_index<NB>(ti, tj)]) : "v"(pos[ti][g]), "v"(pos[tj][g]));
         mfma_drain(acc);
       }
     }
@@ -311,7 +312,7 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
   }
 
   // let the last MFMAs retire before their results are read (no hazard padding around inline asm)
-  if constexpr (NB <= 8) mfma_drain(acc);
+  mfma_drain(acc);
   if constexpr (NW == 1 && NB <= 6) {
     if (factor) {      // A_r = U^T U in registers; what is written below is then U^T (= L, packed by columns)
       const int bad = chol_tiles<NB>(acc, q, c, p.r);
@@ -372,15 +373,18 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
 // workgroup is 4 waves = 4/NW samples.
+// NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
+// workgroup is max(4, NW) waves = max(4, NW)/NW samples.
 template <int NB, int NW>
-__global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+__global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                        int* __restrict__ info) {
-  __shared__ double th[4][32];
+  constexpr int WPB = NW > 4 ? NW : 4;
+  __shared__ double th[WPB][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t s = (int64_t)blockIdx.x * (4 / NW) + wave / NW;
+  trace_begin(p.trace, blockIdx.x);
+  const int64_t s = (int64_t)blockIdx.x * (WPB / NW) + wave / NW;
   if (s >= S) return;                       // no block-wide barrier below
-  // (no s_setprio: measured)
   if (lane == 0) th[wave][0] = 1.0;
   if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
   __builtin_amdgcn_wave_barrier();
@@ -390,14 +394,26 @@ __global__ __launch_bounds__(256, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev
   } else if constexpr (NW == 2) {
     if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br, factor, info);
     else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br, factor, info);
-  } else {
+  } else if constexpr (NW == 4) {
     switch (wave % 4) {
       case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info); break;
       case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info); break;
       case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info); break;
       default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info); break;
     }
+  } else {
+    switch (wave % 8) {
+      case 0: rom_proj_body<NB, 8, 0>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 1: rom_proj_body<NB, 8, 1>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 2: rom_proj_body<NB, 8, 2>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 3: rom_proj_body<NB, 8, 3>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 4: rom_proj_body<NB, 8, 4>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 5: rom_proj_body<NB, 8, 5>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 6: rom_proj_body<NB, 8, 6>(p, thw, s, lane, Ar, Br, factor, info); break;
+      default: rom_proj_body<NB, 8, 7>(p, thw, s, lane, Ar, Br, factor, info); break;
+    }
   }
+  trace_end(p.trace, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -440,7 +456,7 @@ __device__ __forceinline__ void lds_chunk_compute(const double* __restrict__ buf
 }
 
 template <int NB, int WPB>      // WPB waves (= samples) per workgroup share each staged chunk
-__global__ __launch_bounds__(64 * WPB, (WPB == 8 ? 2 : 1)) void rom_proj_lds_kernel(RomDev p, const int* __restrict__ ch_nt,
+__global__ __launch_bounds__(64 * WPB, 1) void rom_proj_lds_kernel(RomDev p, const int* __restrict__ ch_nt,
                                                               const int* __restrict__ ch_nks,
                                                               const int* __restrict__ ch_off,
                                                               const int* __restrict__ ch_bytes,
@@ -454,6 +470,7 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 8 ? 2 : 1)) void rom_proj_lds_ker
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t s = (int64_t)blockIdx.x * WPB + wave;
   const bool live = s < S;
+  trace_begin(p.trace, blockIdx.x);
   const long long probe_t0 = __builtin_amdgcn_s_memtime(), probe_r0 = __builtin_amdgcn_s_memrealtime();
   __builtin_amdgcn_s_setprio(3);
   double* thw = th + wave * 32;
@@ -535,15 +552,20 @@ __global__ __launch_bounds__(64 * WPB, (WPB == 8 ? 2 : 1)) void rom_proj_lds_ker
     x += __shfl_xor(x, 32);
     if (q == 0) Br[s * p.rp + 16 * b + c] = x;
   }
+  trace_end(p.trace, blockIdx.x);
 }
 
 template <int NB>
 static int launch_proj_lds(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                            hipStream_t st) {
-  constexpr int WPB = 4;
   const size_t lds = 2 * ROM_CHUNK_BYTES + 8 * 32 * sizeof(double);
-  hipLaunchKernelGGL((rom_proj_lds_kernel<NB, WPB>), dim3((unsigned)((S + WPB - 1) / WPB)), dim3(64 * WPB), lds, st, p, p.ch_nt, p.ch_nks,
-                     p.ch_off, p.ch_bytes, p.tvc, theta, S, Ar, Br, factor, info);
+  static const int wpb = getenv("FINROM_PROJ_LDS") ? atoi(getenv("FINROM_PROJ_LDS")) : 4;
+  if (wpb == 8)
+    hipLaunchKernelGGL((rom_proj_lds_kernel<NB, 8>), dim3((unsigned)((S + 7) / 8)), dim3(512), lds, st, p, p.ch_nt, p.ch_nks,
+                       p.ch_off, p.ch_bytes, p.tvc, theta, S, Ar, Br, factor, info);
+  else
+    hipLaunchKernelGGL((rom_proj_lds_kernel<NB, 4>), dim3((unsigned)((S + 3) / 4)), dim3(256), lds, st, p, p.ch_nt, p.ch_nks,
+                       p.ch_off, p.ch_bytes, p.tvc, theta, S, Ar, Br, factor, info);
   FR_HIP(hipGetLastError());
   return 0;
 }
@@ -566,12 +588,13 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
   }
   dim3 block(256);
 #define FR_CASE(N, W)                                                                              \
-  case N: hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + (4 / W) - 1) / (4 / W))), \
-                             block, 0, st, p, theta, S, Ar, Br, factor, info); break;
+  case N: { constexpr int wpb = W > 4 ? W : 4; constexpr int spb = wpb / W;                        \
+            hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + spb - 1) / spb)),     \
+                               dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info); } break;
   switch (p.NB) {
     FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(5, 1) FR_CASE(6, 1)
     FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
-    FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 4)
+    FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 4)   // 8 waves/sample measured slower (each wave rebuilds the slab)
     default:
       set_error("rom_proj: basis size " + std::to_string(p.r) + " > 208 not supported");
       return FINROM_ERR_UNSUPPORTED;

@@ -13,7 +13,11 @@ from . import _ffi
 from ._ffi import DeviceBuffer, FomDesc, FomGradDesc, RomDesc, check, f64, i32, lib
 
 
-ROW_CACHE_SLOTS = 42     # LDS row cache of the FOM interpreter: (42+2) x 512 B = 22 KiB per wave, 7 waves per CU (154 KiB)
+import os as _os
+# LDS row cache of the FOM interpreter: (slots+2) x 512 B per wave.  42 -> 22 KiB, 7 waves per CU (154 KiB);
+# 72 -> 37 KiB, 4 waves per CU.  FWD_CHUNK = ops per prefetch chunk of the forward stream (8 or 16).
+ROW_CACHE_SLOTS = int(_os.environ.get("FINROM_ROW_CACHE", "40"))
+FWD_CHUNK = int(_os.environ.get("FINROM_FWD_CHUNK", "8"))
 
 
 def _is_torch(x):
@@ -88,10 +92,10 @@ class FomEngine:
         def D(a):
             a, p = f64(a); keep.append(a); return p
 
-        streams = plan.op_streams(ROW_CACHE_SLOTS, np.asarray(rhs)[plan.perm])
+        streams = plan.op_streams(ROW_CACHE_SLOTS, np.asarray(rhs)[plan.perm], FWD_CHUNK)
         fk, fa, fb, fd = streams["fwd"]; bk, ba, bb, bd = streams["bwd"]
         d = FomDesc(n=plan.n, nnzL=plan.nnzL, xdim=self.xdim, n_obs=self.n_obs, nasm=len(aidx),
-                    n_alist=len(streams["a_list"]), cache_slots=ROW_CACHE_SLOTS, nops_fwd=len(fk), nops_bwd=len(bk),
+                    n_alist=len(streams["a_list"]), cache_slots=ROW_CACHE_SLOTS, fwd_chunk=FWD_CHUNK, nops_fwd=len(fk), nops_bwd=len(bk),
                     a_list=I(streams["a_list"]), asm_c0=D(c0), asm_ptr=I(aptr), asm_idx=I(aidx), asm_w=D(aw),
                     rhs=D(np.asarray(rhs)[plan.perm]),
                     fwd_kind=I(fk), fwd_a=I(fa), fwd_b=I(fb), fwd_d=I(fd),

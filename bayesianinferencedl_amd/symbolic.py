@@ -219,13 +219,14 @@ class CholeskyPlan:
         cc = np.diff(self.col_ptr).astype(np.int64) + 1
         return int((cc * cc).sum())
 
-    def op_streams(self, cache_slots, rhs_perm=None):
-        """Op streams of the device interpreter (cached per cache size and load pattern)."""
+    def op_streams(self, cache_slots, rhs_perm=None, fwd_chunk=None):
+        """Op streams of the device interpreter (cached per cache size, chunk size and load pattern)."""
+        fwd_chunk = CHUNK if fwd_chunk is None else fwd_chunk
         nz = None if rhs_perm is None else (np.asarray(rhs_perm) != 0.0)
-        key = (cache_slots, None if nz is None else nz.tobytes())
+        key = (cache_slots, fwd_chunk, None if nz is None else nz.tobytes())
         cache = self.__dict__.setdefault("_streams", {})
         if key not in cache:
-            cache[key] = build_op_streams(self, cache_slots, nz)
+            cache[key] = build_op_streams(self, cache_slots, nz, fwd_chunk)
         return cache[key]
 
     def entry_table(self, c0_csr, W_csr):
@@ -268,7 +269,8 @@ OPB_NOP, OPB_WFMA, OPB_WSET, OPB_WFIN = 0, 1, 3, 5
 
 
 class _Emitter:
-    def __init__(self, nvals, pad_b=-1, distance=2):
+    def __init__(self, nvals, pad_b=-1, distance=2, chunk=CHUNK):
+        self.chunk = chunk
         self.pad_b = pad_b                                   # b field of padding ops (forward: the ZERO slot)
         self.distance = distance                             # chunks between a store and the first fetch of the value
         self.kind, self.a, self.b, self.d = [], [], [], []
@@ -280,17 +282,17 @@ class _Emitter:
     def emit(self, kind, a=-1, b=-1, d=-1, loads=(), stores=()):
         need = 0
         for g in loads:
-            need = max(need, (self.store_chunk[g] + self.distance) * CHUNK)
+            need = max(need, (self.store_chunk[g] + self.distance) * self.chunk)
         while self.pos() < need:
             self.kind.append(0); self.a.append(-1); self.b.append(self.pad_b); self.d.append(-1)
-        c = self.pos() // CHUNK
+        c = self.pos() // self.chunk
         self.kind.append(kind); self.a.append(a); self.b.append(b); self.d.append(d)
         for g in stores:
             self.store_chunk[g] = c
 
     def arrays(self):
         n = self.pos()
-        pad = (-n) % (2 * CHUNK) + 2 * CHUNK          # whole number of chunk pairs + one spare pair
+        pad = (-n) % (2 * self.chunk) + 2 * self.chunk          # whole number of chunk pairs + one spare pair
         k = np.asarray(self.kind + [0] * pad, np.int32)
         a = np.asarray(self.a + [-1] * pad, np.int32)
         b = np.asarray(self.b + [self.pad_b] * pad, np.int32)
@@ -298,9 +300,10 @@ class _Emitter:
         return k, a, b, d
 
 
-def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
-    """-> dict(fwd=(kind, a, b, d), bwd=(kind, a, b, d), a_list=entries of L that carry an A value).
-    rhs_nonzero[i] (permuted order): rows whose load F_i may be non-zero (None = all)."""
+def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, fwd_chunk: int = CHUNK):
+    """-> dict(fwd=(kind, a, b, d), bwd=(kind, a, b, d), a_list=entries of L that carry an A value, fwd_chunk).
+    rhs_nonzero[i] (permuted order): rows whose load F_i may be non-zero (None = all).  fwd_chunk = ops per
+    prefetch chunk of the forward stream (8 or 16; the backward stream always uses CHUNK)."""
     n, nnzL = plan.n, plan.nnzL
     row_ptr, ent_col = plan.row_ptr.astype(np.int64), plan.ent_col.astype(np.int64)
     pair_ptr = plan.pair_ptr.astype(np.int64)
@@ -321,7 +324,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
 
     # ---------------- forward: factorisation + L y = F -----------------------------------
     NEG1, ZERO = cache_slots, cache_slots + 1
-    em = _Emitter(nnzL + 2 * n, pad_b=ZERO)
+    em = _Emitter(nnzL + 2 * n, pad_b=ZERO, chunk=fwd_chunk)
     done_chunk = np.zeros(n, np.int64)
     remaining = ndeps.copy()
     eligible = [(-height[i], i) for i in range(n) if remaining[i] == 0]
@@ -329,7 +332,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
     waiting = []          # (ready_chunk, -height, i): eligible but would need padding right now
     order = []
     while eligible or waiting:
-        cur = em.pos() // CHUNK
+        cur = em.pos() // fwd_chunk
         while waiting and waiting[0][0] <= cur:
             _, nh, i = heapq.heappop(waiting)
             heapq.heappush(eligible, (nh, i))
@@ -371,7 +374,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
                 em.emit(OP_LDX, a=e, loads=(e,))
                 em.emit(OP_FMAX, a=yk, loads=(yk,))
         em.emit(OP_FINY, d=YV + i, stores=(YV + i,))
-        done_chunk[i] = (em.pos() - 1) // CHUNK
+        done_chunk[i] = (em.pos() - 1) // fwd_chunk
         for u in users[i]:
             remaining[u] -= 1
             if remaining[u] == 0:
@@ -425,7 +428,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None):
     assert cnt == n
     bwd = emb.arrays()
     a_list = np.nonzero(plan.a_ent >= 0)[0].astype(np.int32)
-    return {"fwd": fwd, "bwd": bwd, "a_list": a_list}
+    return {"fwd": fwd, "bwd": bwd, "a_list": a_list, "fwd_chunk": fwd_chunk}
 
 
 def build_resolve_stream(plan: "CholeskyPlan", base: int):
@@ -483,9 +486,9 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
     G[:nnzL] = A_entries
     rc = np.zeros(cache_slots + 2); rc[cache_slots] = -1.0
 
-    def run(stream, backward):
+    def run(stream, backward, CH):
         kind, a, b, d = stream
-        nch = len(kind) // CHUNK
+        nch = len(kind) // CH
         acc = 0.0
         inv = 0.0
         xreg = 0.0
@@ -493,7 +496,7 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
         def fetch(c):
             if c >= nch:
                 return None
-            sl = slice(c * CHUNK, (c + 1) * CHUNK)
+            sl = slice(c * CH, (c + 1) * CH)
             va = G[np.maximum(a[sl], 0)].copy()
             vb = G[np.maximum(b[sl], 0)].copy() if backward else None
             return va, vb
@@ -503,8 +506,8 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
                 cur = fetch(c)                      # backward: chunk c is fetched right before it executes
             else:
                 cur, nxt = nxt, fetch(c + 1)        # forward: chunk c+1 is fetched BEFORE chunk c executes
-            for u in range(CHUNK):
-                t = c * CHUNK + u
+            for u in range(CH):
+                t = c * CH + u
                 k, ld = kind[t], cur[0][u]
                 if backward:
                     if k == OPB_WSET: acc = ld
@@ -521,6 +524,6 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
                         dd = np.sqrt(acc); inv = 1.0 / dd; G[d[t]] = dd; G[nnzL + b[t]] = inv; acc = 0.0
                     elif k == OP_YSET: acc = rhs_perm[d[t]]
                     elif k == OP_FINY: G[d[t]] = acc * inv; acc = 0.0
-    run(streams["fwd"], False)
-    run(streams["bwd"], True)
+    run(streams["fwd"], False, streams.get("fwd_chunk", CHUNK))
+    run(streams["bwd"], True, CHUNK)
     return G[nnzL + n:].copy()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 1
+#define FINROM_ABI_VERSION 2
 
 typedef enum {
   FINROM_OK = 0,
@@ -86,7 +86,7 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
  * The numeric phase is a schedule interpreter: per sample it keeps a value vector
  *   G = [ L entries (nnzL, initially the assembled A_e) | 1/L_ii (n) | y, then w (n) ]
  * and executes two op streams (factorisation + L y = F, then L^T w = y).  A wave (64 samples,
- * lane = sample) fetches the global operands of chunk c+1 (8 ops) before it executes chunk c,
+ * lane = sample) fetches the global operands of chunk c+1 (fwd_chunk = 8 or 16 ops) before it executes chunk c,
  * so the host must order/pad the forward stream such that a value stored in chunk c is not loaded
  * before chunk c+2 (the backward stream is fetched chunk by chunk: not before c+1); checked at create.  Ops (kind, a, b, d), acc = per-sample accumulator,
  * rc = the LDS cache of the row being eliminated (cache_slots entries):
@@ -105,9 +105,11 @@ typedef struct {
   int32_t n_obs;           /* rows of the observation operator */
   int32_t nasm;            /* entries of asm_idx / asm_w */
   int32_t n_alist;         /* entries of L that carry a value of A */
-  int32_t cache_slots;     /* LDS row-cache slots the forward stream assumes (1..64) */
-  int32_t nops_fwd;        /* multiple of 16 (two 8-op chunks), the last 16 ops are padding */
-  int32_t nops_bwd;        /* same */
+  int32_t cache_slots;     /* LDS row-cache slots the forward stream assumes (1..126): (cache_slots+2)*512 B of LDS
+                              per wave decide how many interpreter waves share a CU (42 -> 7, 72 -> 4) */
+  int32_t fwd_chunk;       /* ops per prefetch chunk of the forward stream: 8 or 16 */
+  int32_t nops_fwd;        /* multiple of 2*fwd_chunk, the last 2*fwd_chunk ops are padding */
+  int32_t nops_bwd;        /* multiple of 16 (two 8-op chunks), the last 16 ops are NOPs */
   const int32_t* a_list;   /* [n_alist] entry indices, ascending */
   const double*  asm_c0;   /* [nnzL] */
   const int32_t* asm_ptr;  /* [nnzL+1] */
