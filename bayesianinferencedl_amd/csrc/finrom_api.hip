@@ -179,6 +179,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
     auto need = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 2 <= c; };
     for (int t = 0; t < a->nops_fwd; ++t) {
       const int k = a->fwd_kind[t], A = a->fwd_a[t], B = a->fwd_b[t], D = a->fwd_d[t], c = t / a->fwd_chunk;
+      if (A < -1 || A >= gsize) return bad("forward op operand index");     // fetched for every op, used or not
       switch (k) {
         case 0: if ((A >= 0 && !need(A, c)) || A < -1 || B < 0 || B >= a->cache_slots + 2) return bad("forward FMA op"); break;
         case 3: case 4: if (!need(A, c)) return bad("forward LDX/FMAX op"); break;
@@ -194,6 +195,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
     auto need1 = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 1 <= c; };   // backward: fetched per chunk
     for (int t = 0; t < a->nops_bwd; ++t) {
       const int k = a->bwd_kind[t], A = a->bwd_a[t], B = a->bwd_b[t], D = a->bwd_d[t], c = t / VM_CHUNK;
+      if (A < -1 || A >= gsize || B < -1 || B >= gsize) return bad("backward op operand index");
       switch (k) {
         case 0: break;
         case 1: if (!need1(A, c) || !need1(B, c)) return bad("backward WFMA op"); break;
@@ -319,6 +321,7 @@ int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* a) {
     auto need1 = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 1 <= c; };
     for (int t = 0; t < a->nops_res; ++t) {
       const int k = a->res_kind[t], A = a->res_a[t], B = a->res_b[t], D = a->res_d[t], c = t / VM_CHUNK;
+      if (A < -1 || A >= gsize || B < -1 || B >= gsize) return bad("resolve op operand index");
       switch (k) {
         case 0: break;
         case 1: if (!need1(A, c) || !need1(B, c)) return bad("WFMA op"); break;

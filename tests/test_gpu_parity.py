@@ -219,3 +219,79 @@ def test_fom_adjoint_gradient_parity(problems, spaces):
     g_field = fo.gradient(fo.nine_param_to_function(k9[2]), data)
     N9 = spaces(12).operators().N9
     assert np.linalg.norm(r9["grad"][2] - g_field @ N9) < 1e-9 * np.linalg.norm(g_field @ N9)
+
+
+@pytest.mark.parametrize("S", [0, 1, 63, 64, 65, 129])
+def test_edge_batch_sizes(problems, spaces, S):
+    """Empty, single and ragged batches (the kernels work on blocks of 64 samples; the tail block replicates
+    the last sample and must not write past the outputs)."""
+    from bayesianinferencedl_amd.pairs import FinPairSolver
+    m = 4
+    prob = problems(m); V = spaces(m)
+    phi = oracle_basis(prob, 8)
+    fo = O.FinOracle(prob); ro = O.AffineROMOracle(prob, phi)
+    rng = np.random.default_rng(11)
+    X = rng.uniform(0.1, 10.0, (S, 5))
+    res = FinPairSolver(V, phi, params="five").solve_pairs(X)
+    assert np.asarray(res["qoi"]).shape == (S, 9) and np.asarray(res["qoi_r"]).shape == (S, 9)
+    if S == 0:
+        return
+    assert (np.asarray(res["info"]) == 0).all()
+    for i in {0, S - 1}:
+        k = fo.five_param_to_function(X[i])
+        q = fo.B_obs @ fo.forward(k)
+        qr = ro.qoi_reduced(ro.forward_reduced(k))
+        assert np.linalg.norm(np.asarray(res["qoi"])[i] - q) < TOL * np.linalg.norm(q)
+        assert np.linalg.norm(np.asarray(res["qoi_r"])[i] - qr) < TOL * np.linalg.norm(qr)
+
+
+def test_fwd_chunk_16_stream_gives_the_same_solution(problems, spaces, monkeypatch):
+    """The interpreter is instantiated for 8- and 16-op prefetch chunks (finrom_fom_desc.fwd_chunk)."""
+    import bayesianinferencedl_amd.engine as E
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.fom.thermal_fin import get_space
+    m = 4
+    prob = problems(m)
+    fo = O.FinOracle(prob)
+    rng = np.random.default_rng(4)
+    X = rng.uniform(0.1, 10.0, (70, 9))
+    monkeypatch.setattr(E, "FWD_CHUNK", 16)
+    monkeypatch.setattr(E, "ROW_CACHE_SLOTS", 5)          # also exercises the LDX / FMAX ops
+    res = Fin(get_space(40, m=m)).forward_batch(X, want_w=True, params="nine")
+    W = np.array([fo.forward(fo.nine_param_to_function(X[i])) for i in range(8)])
+    assert rel(np.asarray(res["w"])[:8], W) < TOL
+
+
+def test_create_rejects_corrupt_descriptors(spaces):
+    """Descriptor indices are validated on the host: a bad index is an error code, never a GPU fault."""
+    import ctypes as C
+    from bayesianinferencedl_amd import _ffi
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    lib = _ffi.lib()
+    real = lib.finrom_fom_create
+    seen = {}
+
+    def spy(dref, href):                 # the descriptor's arrays are alive only during the engine's own call
+        d = dref._obj
+        h = C.c_void_p()
+        old = d.fwd_a[5]
+        d.fwd_a[5] = d.nnzL + 3 * d.n + 7                     # load index outside the value vector
+        seen["bad_index"] = (real(C.byref(d), C.byref(h)), lib.finrom_last_error())
+        d.fwd_a[5] = old
+        old_chunk = d.fwd_chunk
+        d.fwd_chunk = 12
+        seen["bad_chunk"] = real(C.byref(d), C.byref(h))
+        d.fwd_chunk = old_chunk
+        old = d.perm[0]
+        d.perm[0] = d.perm[1]                                 # not a permutation
+        seen["bad_perm"] = real(C.byref(d), C.byref(h))
+        d.perm[0] = old
+        return real(dref, href)
+    try:
+        lib.finrom_fom_create = spy
+        res = Fin(spaces(4)).forward_batch(np.full((3, 9), 1.0), params="nine")
+    finally:
+        lib.finrom_fom_create = real
+    assert seen["bad_index"][0] != 0 and b"invalid" in seen["bad_index"][1]
+    assert seen["bad_chunk"] != 0 and seen["bad_perm"] != 0
+    assert (np.asarray(res["info"]) == 0).all()

@@ -93,17 +93,17 @@ def test_cholesky_plan_schedule_reproduces_the_solve(spaces, ordering):
     assert plan.npairs == sum(len(a) for a in [plan.pair_a])
 
 
-@pytest.mark.parametrize("m,cache", [(4, 36), (4, 3), (12, 36)])
-def test_op_streams_replay_with_prefetch_semantics(spaces, m, cache):
+@pytest.mark.parametrize("m,cache,fwd_chunk", [(4, 36, 8), (4, 3, 8), (12, 36, 8), (4, 5, 16), (12, 40, 16)])
+def test_op_streams_replay_with_prefetch_semantics(spaces, m, cache, fwd_chunk):
     """The device interpreter fetches the operands of chunk c+1 before executing chunk c; the
     NumPy replay does the same, so a scheduling/padding bug shows up as a wrong solution."""
     from bayesianinferencedl_amd.symbolic import CholeskyPlan, build_op_streams, replay_op_streams, CHUNK
     ops = spaces(m).operators()
     plan = CholeskyPlan(ops.indptr, ops.indices, ops.n)
-    st = build_op_streams(plan, cache)
-    for name in ("fwd", "bwd"):
+    st = build_op_streams(plan, cache, None, fwd_chunk)
+    for name, ch in (("fwd", fwd_chunk), ("bwd", CHUNK)):
         k = st[name][0]
-        assert len(k) % (2 * CHUNK) == 0 and (k[-2 * CHUNK:] == 0).all()
+        assert len(k) % (2 * ch) == 0 and (k[-2 * ch:] == 0).all()
     rng = np.random.default_rng(2)
     kf = np.exp(0.3 * rng.standard_normal(ops.n))
     vals = ops.fom_values(kf)
