@@ -3,7 +3,7 @@ surface (fom/forward_solve.py::Fin).  Every solve goes through libfinrom_hip.so;
 methods are batches of one.
 
 Reference methods mirrored (file fom/forward_solve.py): __init__ :98-265 (hot-path subset),
-forward :270-291, forward_five_param :267-268, qoi_operator :408-412, reduced_qoi_operator
+forward :270-291, gradient :293-322, sensitivity :324-342, reg/grad_reg :186-191, forward_five_param :267-268, qoi_operator :408-412, reduced_qoi_operator
 :415-419, reduced_forward :421-452, r_fwd_no_full :454-464, subfin_avg_op :466-480,
 nine_param_to_function :482-486, observation_operator :488-511.  five_param_to_function
 follows the only surviving definition, fom/forward_solve_petsc.py:243-260."""
@@ -105,6 +105,43 @@ class Fin:
         if res["info"][0]:
             raise np.linalg.LinAlgError("FOM operator not positive definite for this conductivity")
         return res["grad"][0]
+
+    def sensitivity(self, k):
+        """Jacobian of the parameter-to-observable map, [n_obs, n] (:324-342): one adjoint solve per observation.
+        On the device: one forward solve for the observables, then a batch of n_obs value-and-gradient evaluations
+        whose residuals are the unit vectors (data_o = B_obs w - e_o)."""
+        self._k.assign(k)
+        return self.sensitivity_batch(as_nodal(self._k)[None, :])[0]
+
+    def sensitivity_batch(self, K, params=None):
+        """K [S, xdim] -> dq/dx [S, n_obs, xdim]."""
+        K = np.ascontiguousarray(K, dtype=np.float64)
+        S = K.shape[0]
+        fwd = self.forward_batch(K, want_w=False, params=params)
+        if np.any(np.asarray(fwd["info"]) != 0):
+            raise np.linalg.LinAlgError("FOM operator not positive definite for this conductivity")
+        q = np.asarray(fwd["qoi"])
+        data = (q[:, None, :] - np.eye(self.n_obs)[None, :, :]).reshape(S * self.n_obs, self.n_obs)
+        g = self.gradient_batch(np.repeat(K, self.n_obs, axis=0), data, params=params)["grad"]
+        return np.asarray(g).reshape(S, self.n_obs, -1)
+
+    # ---- Tikhonov regulariser (:186-191).  The reference exposes UFL forms that callers assemble after assigning
+    # solver._k (bayesian_inference/estimate_MAP.py:94-109); here they are evaluated for the current _k.
+    gamma = 1e-6
+
+    def _unit_stiffness(self):
+        if getattr(self, "_K1", None) is None:
+            self._K1 = self.ops.csr(self.ops.sub_vals.sum(axis=0))      # int grad u . grad v dx
+        return self._K1
+
+    @property
+    def reg(self):
+        k = as_nodal(self._k)
+        return 0.5 * self.gamma * float(k @ (self._unit_stiffness() @ k))
+
+    @property
+    def grad_reg(self):
+        return self.gamma * (self._unit_stiffness() @ as_nodal(self._k))
 
     def forward_five_param(self, k_s):
         return self.forward(self.five_param_to_function(k_s))

@@ -291,6 +291,29 @@ class FinOracle:
                 g[t] += val
         return g
 
+    def sensitivity(self, k_nodal):                          # :324-342 (one adjoint solve per observation)
+        A = self.prob.assemble_fom(np.asarray(k_nodal, float)).tocsc()
+        z = spl.spsolve(A, self.B)
+        J = np.zeros((self.B_obs.shape[0], self.prob.n))
+        for o in range(self.B_obs.shape[0]):
+            v = spl.spsolve(A, -np.asarray(self.B_obs[o]).ravel())
+            for c, tri in enumerate(self.prob.cells):
+                val = v[tri] @ self.prob.Kc[c] @ z[tri] / 3.0
+                for t in tri:
+                    J[o, t] += val
+        return J
+
+    def reg(self, k_nodal, gamma=1e-6):                      # :190  0.5 gamma int |grad k|^2
+        k = np.asarray(k_nodal, float)
+        return 0.5 * gamma * sum(k[tri] @ self.prob.Kc[c] @ k[tri] for c, tri in enumerate(self.prob.cells))
+
+    def grad_reg(self, k_nodal, gamma=1e-6):                 # :189  gamma int grad k . grad v
+        k = np.asarray(k_nodal, float)
+        g = np.zeros(self.prob.n)
+        for c, tri in enumerate(self.prob.cells):
+            g[tri] += gamma * (self.prob.Kc[c] @ k[tri])
+        return g
+
     def qoi_operator(self, w):                               # :408-412
         return self.B_obs @ w
 
