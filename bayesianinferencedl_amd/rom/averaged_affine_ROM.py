@@ -3,7 +3,7 @@ the reference's call surface (rom/averaged_affine_ROM.py::AffineROMFin).
 
 Reference methods mirrored (file rom/averaged_affine_ROM.py): __init__ :57-235 (forward-path
 subset), forward :237-258, forward_reduced :260-276, forward_nine_param_reduced :278-310,
-qoi :312-320, qoi_reduced :323-333, set_data/set_dl_model :398-402, subfin_avg_op :404-418,
+qoi :312-320, qoi_reduced :323-333, grad_reduced :335-356, grad_romml :358-396, set_data/set_dl_model :398-402, subfin_avg_op :404-418,
 observation_operator :420-445.  The reduced system is least-squares Petrov-Galerkin
 (psi = A Phi, A_r = psi^T psi, :295-297), NOT Galerkin."""
 from __future__ import annotations
@@ -158,6 +158,33 @@ class AffineROMFin:
         dJ_dk = np.dot(res["g_theta"][0], self.dsigma_dk)       # [9] x [9, n]  (:349-351)
         self.rom_grad_time += (time.time() - t_i)
         return dJ_dk, float(res["J"][0])
+
+    def grad_romml_batch(self, K, data=None):
+        """Batched grad_romml (:358-396): ROM + learned-error value and gradient.  loss = 1/2 |data - (B_obs Phi w_r + e_NN(k))|^2;
+        its gradient is the ROM adjoint gradient for the shifted data (data - e_NN) plus the network's vector-Jacobian
+        product.  K [S, n] -> dict(grad [S, n], loss [S], qoi_r, e_NN, info)."""
+        if self.dl_model is None:
+            raise ValueError("grad_romml needs an error model (set_dl_model)")
+        K = np.ascontiguousarray(K, dtype=np.float64)
+        data = np.asarray(self.data if data is None else data, dtype=np.float64)
+        t_i = time.time()
+        e_nn = np.asarray(self.dl_model.predict(K), dtype=np.float64)
+        self.romml_grad_time_dl += (time.time() - t_i)
+        t_i = time.time()
+        res = self.grad_reduced_batch(K, data=np.broadcast_to(data, e_nn.shape) - e_nn)
+        f_x = np.asarray(res["g_theta"]) @ self.dsigma_dk                              # :376-378
+        self.romml_grad_time += (time.time() - t_i)
+        resid = np.broadcast_to(data, e_nn.shape) - (np.asarray(res["qoi_r"]) + e_nn)
+        t_i = time.time()
+        nn_grad = -np.asarray(self.dl_model.vjp(K, resid), dtype=np.float64)           # d loss / d input (:226-228)
+        self.romml_grad_time_dl += (time.time() - t_i)
+        return {"grad": f_x + nn_grad, "loss": np.asarray(res["J"]), "qoi_r": res["qoi_r"], "e_NN": e_nn, "info": res["info"]}
+
+    def grad_romml(self, k):
+        res = self.grad_romml_batch(as_nodal(k)[None, :])
+        if res["info"][0]:
+            raise np.linalg.LinAlgError("reduced operator not positive definite")
+        return res["grad"][0], float(res["loss"][0])
 
     def set_data(self, data):
         self.data = data

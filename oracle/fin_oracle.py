@@ -422,6 +422,20 @@ class AffineROMOracle:
         return dJ_dk, J
 
 
+def grad_romml_oracle(rom: "AffineROMOracle", model, k_nodal):
+    """rom/averaged_affine_ROM.py:358-396 with an error model exposing predict / vjp (float32 like the Keras model)."""
+    k_nodal = np.asarray(k_nodal, float)
+    w_r, A_r, B_r, psi = rom.forward_nine_param_reduced(rom.subfin_avg_op(k_nodal), True)
+    e_nn = np.asarray(model.predict(k_nodal[None, :])[0], float)
+    obs = rom.B_obs_phi @ w_r
+    resid = rom.data - (obs + e_nn)
+    v_r = np.linalg.solve(A_r.T, rom.B_obs_phi.T @ resid)
+    A_phi_w_r = np.dot(rom.dA_dsigmak_phi, w_r).T
+    f_x = ((psi @ v_r) @ A_phi_w_r) @ rom.dsigma_dk
+    nn = -np.asarray(model.vjp(k_nodal[None, :], resid[None, :])[0], float)
+    return f_x + nn, 0.5 * float(resid @ resid)
+
+
 def lspg_longdouble(prob: FinProblem, phi, theta):
     """Extended-precision (x87 80-bit) LSPG normal equations + Cholesky: tolerance 'truth'."""
     A = prob.assemble_affine(theta).toarray().astype(np.longdouble)

@@ -192,3 +192,25 @@ def test_reference_import_paths_resolve():
     import bayesianinferencedl_amd.fom.forward_solve as impl
     assert Fin is impl.Fin and callable(get_space) and callable(make_cov_chol) and callable(gen_affine_avg_rom_dataset)
     assert AffineROMFin.__module__ == "bayesianinferencedl_amd.rom.averaged_affine_ROM"
+
+
+def test_error_model_vjp_matches_finite_differences():
+    """deep_learning/dl_model.py::ResBnFcModel (stand-in for the reference's res_bn_fc_model): the vector-Jacobian product
+    behind tf.gradients(loss, model.input) against central differences (fp32 network: loose tolerance)."""
+    from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel
+    rng = np.random.default_rng(0)
+    m = ResBnFcModel(n_in=30, n_out=9, n_layers=3, n_weights=16, seed=3)
+    for u in m.units + [m.head]:                       # non-trivial batch-norm statistics
+        u["gamma"] = rng.uniform(0.5, 1.5, u["gamma"].shape).astype(np.float32)
+        u["beta"] = rng.normal(0, 0.3, u["beta"].shape).astype(np.float32)
+        u["mean"] = rng.normal(0, 0.3, u["mean"].shape).astype(np.float32)
+        u["var"] = rng.uniform(0.5, 2.0, u["var"].shape).astype(np.float32)
+    x = rng.normal(0, 1, (2, 30))
+    up = rng.normal(0, 1, (2, 9))
+    g = m.vjp(x, up)
+    assert g.shape == (2, 30) and m.predict([[x[0]]]).shape == (1, 9)
+    eps = 1e-2
+    for j in (0, 7, 29):
+        e = np.zeros(30); e[j] = eps
+        fd = ((m.predict(x + e).astype(np.float64) - m.predict(x - e).astype(np.float64)) / (2 * eps) * up).sum(axis=1)
+        assert np.allclose(fd, g[:, j], rtol=3e-2, atol=3e-3)
