@@ -26,7 +26,8 @@ class FomDesc(C.Structure):
                 ("asm_w", c_f64p), ("rhs", c_f64p),
                 ("fwd_kind", c_i32p), ("fwd_a", c_i32p), ("fwd_b", c_i32p), ("fwd_d", c_i32p),
                 ("bwd_kind", c_i32p), ("bwd_a", c_i32p), ("bwd_b", c_i32p), ("bwd_d", c_i32p),
-                ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p), ("perm", c_i32p)]
+                ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p), ("perm", c_i32p),
+                ("n_imm", C.c_int32), ("imm", c_f64p)]
 
 
 class FomGradDesc(C.Structure):
@@ -101,7 +102,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 2:
+        if L.finrom_version() != 3:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

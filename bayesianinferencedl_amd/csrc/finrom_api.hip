@@ -174,6 +174,8 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   if (a->asm_ptr[0] != 0 || a->asm_ptr[nnzL] != a->nasm) return bad("asm_ptr");
   for (int e = 0; e < nnzL; ++e) if (a->asm_ptr[e + 1] < a->asm_ptr[e]) return bad("asm_ptr");
   for (int t = 0; t < a->nasm; ++t) if (a->asm_idx[t] < 0 || a->asm_idx[t] >= a->xdim) return bad("asm_idx");
+  int fused = 0;
+  if (a->n_imm < 0 || (a->n_imm > 0 && !a->imm)) return bad("imm");
   {
     std::vector<int> stored(gsize, -10);
     auto need = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 2 <= c; };
@@ -186,6 +188,8 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
         case 5: if (!need(A, c) || D < 0 || D >= nnzL || B < -1 || B >= a->cache_slots) return bad("forward FINOFF op"); stored[D] = c; break;
         case 6: if (D < 0 || D >= nnzL || B < 0 || B >= n) return bad("forward FINDIAG op"); stored[D] = c; stored[nnzL + B] = c; break;
         case 7: if (D < 0 || D >= n) return bad("forward YSET op"); break;
+        case 9: if (a->xdim > FOM_MAX_FUSED_X || B < 0 || B >= a->xdim || D < 0 || D >= a->n_imm) return bad("forward XFMA op"); fused = 1; break;
+        case 10: if (a->xdim > FOM_MAX_FUSED_X || D < 0 || D >= a->n_imm) return bad("forward CADD op"); fused = 1; break;
         case 8: if (D < nnzL + n || D >= gsize) return bad("forward FINY op"); stored[D] = c; break;
         default: return bad("forward op kind");
       }
@@ -226,12 +230,14 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   d.has_grad = 0; d.nchunks_res = 0;
   if (const char* ph = getenv("FINROM_FOM_PHASES")) d.debug_phases = atoi(ph);
   std::vector<int> fkb(a->nops_fwd), bkb(a->nops_bwd);
-  // device encoding of the forward stream: load offsets in bytes (padding ops re-read element 0), the common
+  // device encoding of the forward stream: load offsets in bytes, the common
   // multiply-add carries the LDS byte offset of its row-cache slot, every other op kind | (b+1) << 8, and one bit
   // mask per chunk flags the slots that are NOT plain multiply-adds
   std::vector<int> fa2(a->nops_fwd), fmask(a->nops_fwd / a->fwd_chunk, 0);
   for (int t = 0; t < a->nops_fwd; ++t) {
-    fa2[t] = std::max(a->fwd_a[t], 0) * 512;
+    // ops without a global operand (padding, fused-assembly ops) fetch from beyond the buffer's range: the hardware
+    // bounds check returns 0 without touching memory (a real element could be uninitialised: 0 * NaN)
+    fa2[t] = a->fwd_a[t] < 0 ? 0x7FFFFFF0 : a->fwd_a[t] * 512;
     if (a->fwd_kind[t] == 0) fkb[t] = a->fwd_b[t] * 512;
     else { fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8); fmask[t / a->fwd_chunk] |= 1 << (t % a->fwd_chunk); }
   }
@@ -255,6 +261,9 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   if (!rc) rc = up(h->owned, &d.rhs, a->rhs, n);
   if (!rc) rc = up(h->owned, &d.f_a, fa2.data(), fa2.size());
   if (!rc) rc = up(h->owned, &d.f_mask, fmask.data(), fmask.size());
+  d.fused = fused;
+  if (fused && a->n_alist != 0) { finrom_fom_destroy(h); set_error("fom_create: a fused stream must come with n_alist = 0"); return FINROM_ERR_ARG; }
+  if (!rc) rc = up(h->owned, &d.f_imm, a->imm, (size_t)a->n_imm);
   if (!rc) rc = up(h->owned, &d.f_kb, fkb.data(), fkb.size());
   if (!rc) rc = up(h->owned, &d.f_d, a->fwd_d, a->nops_fwd);
   if (!rc) rc = up(h->owned, &d.b_a, a->bwd_a, a->nops_bwd);
@@ -296,10 +305,10 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
       if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
       if ((rc = h->Gw.reserve((size_t)nblk * d.gsize * 64 * sizeof(double)))) return rc;
       if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
-      if ((rc = launch_fom_assemble(d, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
+      if (!d.fused && (rc = launch_fom_assemble(d, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
     }
     if (stages & 2) {
-      if ((rc = launch_fom(d, nblk, Sc, (double*)h->Gw.p, qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
+      if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Gw.p, qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
       if (w && (rc = launch_unpack_w(d, (const double*)h->Gw.p, Sc, w + s0 * d.n, st))) return rc;
     }
   }
@@ -376,8 +385,8 @@ int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int
     double* q = qoi ? qoi + s0 * d.n_obs : nullptr;
     if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
     if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
-    if ((rc = launch_fom_assemble(d, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
-    if ((rc = launch_fom(d, nblk, Sc, (double*)h->Gw.p, q, info ? info + s0 : nullptr, st))) return rc;
+    if (!d.fused && (rc = launch_fom_assemble(d, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
+    if ((rc = launch_fom(d, (const double*)h->xT.p, nblk, Sc, (double*)h->Gw.p, q, info ? info + s0 : nullptr, st))) return rc;
     if ((rc = launch_fom_adjoint(d, nblk, Sc, (double*)h->Gw.p, q, data + (data_per_sample ? s0 * d.n_obs : 0),
                                  data_per_sample ? d.n_obs : 0, (double*)h->gradT.p, J + s0, st))) return rc;
     if ((rc = launch_unpack((const double*)h->gradT.p, Sc, d.xdim, d.xdim, 0, nullptr, grad + s0 * d.xdim, st))) return rc;

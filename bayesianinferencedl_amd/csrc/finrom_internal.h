@@ -69,6 +69,7 @@ __device__ __forceinline__ void trace_end(long long* tr, int64_t wg) {
 }
 
 // ---- FOM ------------------------------------------------------------------------------
+constexpr int FOM_MAX_FUSED_X = 16;   // longest parameter vector the interpreter keeps in LDS (fused assembly)
 constexpr int VM_CHUNK = 8;        // ops whose global operands are fetched together, one chunk ahead
 struct FomDev {
   long long* trace;   // FINROM_TRACE: per-workgroup {start, end (10 ns ticks), HW_ID, XCC_ID}; nullptr = off
@@ -80,6 +81,8 @@ struct FomDev {
   const int* asm_idx; const double* asm_w;            // terms beyond the first four of an entry
   const double* rhs;
   const int* f_a; const int* f_kb; const int* f_d;     // forward stream: load byte offset, LDS byte offset (FMA) or kind | (b+1) << 8, d
+  const double* f_imm;                                 // immediates of the fused-assembly ops
+  int fused;                                           // the forward stream assembles A itself (x in LDS, no pre-pass)
   const int* f_mask;                                   // per chunk: bit u set = slot u is not a plain multiply-add
   const int* b_a; const int* b_kb; const int* b_d;     // backward stream
   const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
@@ -94,7 +97,7 @@ int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, con
 int launch_unpack(const double* srcT, int64_t S, int d, int64_t blk_stride, int off, const int* perm, double* dst, hipStream_t st);
 int launch_pack(const double* x, int64_t S, int d, double* xT, hipStream_t st);
 int launch_fom_assemble(const FomDev& p, const double* xT, int64_t nblk, double* Gw, hipStream_t st);
-int launch_fom(const FomDev& p, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st);
+int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st);
 int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st);
 
 // ---- ROM ------------------------------------------------------------------------------

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void fom_assemble_kernel(FomDev p, const int* 
 // Global operands of chunk c+1 are in flight while chunk c executes (double-buffered in
 // registers); the op descriptors themselves are sequential scalar loads.
 // ---------------------------------------------------------------------------------------
-enum { F_FMA = 0, F_LDX = 3, F_FMAX = 4, F_FINOFF = 5, F_FINDIAG = 6, F_YSET = 7, F_FINY = 8 };
+enum { F_FMA = 0, F_LDX = 3, F_FMAX = 4, F_FINOFF = 5, F_FINDIAG = 6, F_YSET = 7, F_FINY = 8, F_XFMA = 9, F_CADD = 10 };
 enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
 
 // The op arrays are separate __restrict__ kernel parameters on purpose: only then can the compiler
@@ -110,9 +110,10 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
                                                     const int* __restrict__ bKB, const int* __restrict__ bD,
                                                     const double* __restrict__ rhs, const int* __restrict__ obs_ptr,
                                                     const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                    const double* __restrict__ fImm, const double* __restrict__ xT,
                                                     double* __restrict__ Gw, int64_t S,
                                                     double* __restrict__ qoi, int* __restrict__ info) {
-  // LDS: [cache_slots] row cache | NEG1 | ZERO | INV | XREG | BAD, each 64 lanes x 8 B.  The interpreter state that
+  // LDS: [cache_slots] row cache | NEG1 | ZERO | INV | XREG | BAD | x[xdim] (fused assembly only), each 64 lanes x 8 B.  The interpreter state that
   // only the rare ops touch (1/L_ii of the current row, the LDX operand, the failure flag) lives in LDS, not in
   // registers: loop-carried registers that the common multiply-add does not modify cost a register move per
   // unrolled op, and every VALU instruction of this kernel competes with the projection kernel's MFMAs.
@@ -128,6 +129,9 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   rc[S_NEG1 * 64] = -1.0;          // "acc = A_e" is an FMA against it
   rc[S_ZERO * 64] = 0.0;           // padding ops
   rc[S_INV * 64] = 0.0; rc[S_XREG * 64] = 0.0; rc[S_BAD * 64] = 0.0;
+  const int S_X0 = p.cache_slots + 5;
+  if (p.fused)
+    for (int j = 0; j < p.xdim; ++j) rc[(S_X0 + j) * 64] = xT[(blk * p.xdim + j) * 64 + lane];
   double acc = 0.0;
   // operand fetches are buffer loads: descriptor + element offset in SGPRs, lane offset in one VGPR -- no
   // per-load vector address arithmetic
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
     const int* __restrict__ A = fA; const int* __restrict__ KB = fKB; const int* __restrict__ D = fD;
     double bufA[FCH], bufB[FCH];
 #define VM_EXEC_F(buf, c)                                                     \
-  int kbv[FCH];            /* descriptors of the whole chunk: scalar loads */ \
-  _Pragma("unroll") for (int u = 0; u < FCH; ++u) kbv[u] = KB[(c) * FCH + u]; \
+  int kbv[FCH], dv[FCH];   /* descriptors of the whole chunk: scalar loads issued together */ \
+  _Pragma("unroll") for (int u = 0; u < FCH; ++u) { kbv[u] = KB[(c) * FCH + u]; dv[u] = D[(c) * FCH + u]; } \
   const int msk = fM[c];                                                      \
   _Pragma("unroll") for (int u = 0; u < FCH; ++u) {                           \
     const double ld = buf[u];                                                 \
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
     } else {                                                                  \
       const int kb = kbv[u];                                                  \
       const int kind = kb & 255, b = (kb >> 8) - 1;                           \
-      const int d = D[(c) * FCH + u];                                         \
+      const int d = dv[u];                                                    \
       switch (kind) {                                                         \
         case F_LDX: rc[S_XREG * 64] = ld; break;   /* row entry beyond the LDS cache */ \
         case F_FMAX: acc = fma(-rc[S_XREG * 64], ld, acc); break;             \
@@ -182,6 +186,8 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
           acc = 0.0;                                                          \
         } break;                                                              \
         case F_YSET: acc = rhs[d]; break;                                     \
+        case F_XFMA: acc = fma(fImm[d], rc[(S_X0 + b) * 64], acc); break;   /* fused assembly: A_e += w * x_b */ \
+        case F_CADD: acc += fImm[d]; break;                                   \
         case F_FINY: Gs[(int64_t)d * 64 + lane] = acc * rc[S_INV * 64]; acc = 0.0; break; \
         default: break;                                                       \
       }                                                                       \
@@ -261,16 +267,16 @@ int launch_fom_assemble(const FomDev& p, const double* xT, int64_t nblk, double*
   return 0;
 }
 
-int launch_fom(const FomDev& p, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st) {
+int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st) {
   if (nblk == 0) return 0;
   ScopedKernelTimer t(K_FOM, st);
-  const size_t lds = (size_t)(p.cache_slots + 5) * 64 * sizeof(double);
+  const size_t lds = (size_t)(p.cache_slots + 5 + (p.fused ? p.xdim : 0)) * 64 * sizeof(double);
   if (p.fwd_chunk == 16)
     hipLaunchKernelGGL(fom_vm_kernel<16>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.b_a, p.b_kb,
-                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, Gw, S, qoi, info);
+                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, p.f_imm, xT, Gw, S, qoi, info);
   else
     hipLaunchKernelGGL(fom_vm_kernel<8>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.b_a, p.b_kb,
-                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, Gw, S, qoi, info);
+                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, p.f_imm, xT, Gw, S, qoi, info);
   FR_HIP(hipGetLastError());
   return 0;
 }

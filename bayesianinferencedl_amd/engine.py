@@ -18,6 +18,9 @@ import os as _os
 # 72 -> 37 KiB, 4 waves per CU.  FWD_CHUNK = ops per prefetch chunk of the forward stream (8 or 16).
 ROW_CACHE_SLOTS = int(_os.environ.get("FINROM_ROW_CACHE", "40"))
 FWD_CHUNK = int(_os.environ.get("FINROM_FWD_CHUNK", "8"))
+# Parameter vectors of at most FUSED_X_MAX entries (the five / nine fin conductivities) sit in the interpreter's LDS and
+# the op stream assembles A itself (no pre-pass); their slots come out of the row cache so that 7 waves still share a CU.
+FUSED_X_MAX = int(_os.environ.get("FINROM_FUSED_X_MAX", "16"))
 
 
 def _is_torch(x):
@@ -92,15 +95,19 @@ class FomEngine:
         def D(a):
             a, p = f64(a); keep.append(a); return p
 
-        streams = plan.op_streams(ROW_CACHE_SLOTS, np.asarray(rhs)[plan.perm], FWD_CHUNK)
+        fused = self.xdim <= min(FUSED_X_MAX, 16) and ROW_CACHE_SLOTS - self.xdim >= 8
+        slots = ROW_CACHE_SLOTS - (self.xdim if fused else 0)
+        streams = plan.op_streams(slots, np.asarray(rhs)[plan.perm], FWD_CHUNK, (c0, aptr, aidx, aw) if fused else None)
+        self.cache_slots, self.fused, self._streams = slots, fused, streams
         fk, fa, fb, fd = streams["fwd"]; bk, ba, bb, bd = streams["bwd"]
         d = FomDesc(n=plan.n, nnzL=plan.nnzL, xdim=self.xdim, n_obs=self.n_obs, nasm=len(aidx),
-                    n_alist=len(streams["a_list"]), cache_slots=ROW_CACHE_SLOTS, fwd_chunk=FWD_CHUNK, nops_fwd=len(fk), nops_bwd=len(bk),
+                    n_alist=len(streams["a_list"]), cache_slots=slots, fwd_chunk=FWD_CHUNK, nops_fwd=len(fk), nops_bwd=len(bk),
                     a_list=I(streams["a_list"]), asm_c0=D(c0), asm_ptr=I(aptr), asm_idx=I(aidx), asm_w=D(aw),
                     rhs=D(np.asarray(rhs)[plan.perm]),
                     fwd_kind=I(fk), fwd_a=I(fa), fwd_b=I(fb), fwd_d=I(fd),
                     bwd_kind=I(bk), bwd_a=I(ba), bwd_b=I(bb), bwd_d=I(bd),
-                    obs_ptr=I(optr), obs_idx=I(oidx), obs_w=D(ow), perm=I(plan.perm))
+                    obs_ptr=I(optr), obs_idx=I(oidx), obs_w=D(ow), perm=I(plan.perm),
+                    n_imm=len(streams["imm"]), imm=D(streams["imm"]))
         h = C.c_void_p()
         check(lib().finrom_fom_create(C.byref(d), C.byref(h)), "finrom_fom_create")
         self._h = h

@@ -219,14 +219,16 @@ class CholeskyPlan:
         cc = np.diff(self.col_ptr).astype(np.int64) + 1
         return int((cc * cc).sum())
 
-    def op_streams(self, cache_slots, rhs_perm=None, fwd_chunk=None):
-        """Op streams of the device interpreter (cached per cache size, chunk size and load pattern)."""
+    def op_streams(self, cache_slots, rhs_perm=None, fwd_chunk=None, fused_asm=None):
+        """Op streams of the device interpreter (cached per cache size, chunk size, load pattern and -- when the
+        affine assembly is fused into the stream -- value map: fused_asm = entry_table(...) output)."""
         fwd_chunk = CHUNK if fwd_chunk is None else fwd_chunk
         nz = None if rhs_perm is None else (np.asarray(rhs_perm) != 0.0)
-        key = (cache_slots, fwd_chunk, None if nz is None else nz.tobytes())
+        akey = None if fused_asm is None else tuple(np.asarray(a).tobytes() for a in fused_asm)
+        key = (cache_slots, fwd_chunk, None if nz is None else nz.tobytes(), akey)
         cache = self.__dict__.setdefault("_streams", {})
         if key not in cache:
-            cache[key] = build_op_streams(self, cache_slots, nz, fwd_chunk)
+            cache[key] = build_op_streams(self, cache_slots, nz, fwd_chunk, fused_asm)
         return cache[key]
 
     def entry_table(self, c0_csr, W_csr):
@@ -264,6 +266,10 @@ CHUNK = 8
 #   acc -= rc[b] * G[a]        with two constant LDS slots after the row cache: NEG1 (-1.0) and ZERO (0.0),
 # so "acc = A_e" is an FMA against NEG1 (every FIN* op leaves acc = 0) and padding is an FMA against ZERO.
 OP_FMA, OP_LDX, OP_FMAX, OP_FINOFF, OP_FINDIAG, OP_YSET, OP_FINY = 0, 3, 4, 5, 6, 7, 8
+# fused affine assembly (parameter vectors short enough to sit in LDS): the value of A_e is built by the interpreter itself,
+#   XFMA acc += imm[d] * x[b]      CADD acc += imm[d]
+# instead of being fetched from the pre-pass's output ("acc = A_e" FMA against the NEG1 slot)
+OP_XFMA, OP_CADD = 9, 10
 # a row entry beyond the LDS row cache is fetched like any other operand: LDX x = G[a]; FMAX acc -= x * G[a]
 OPB_NOP, OPB_WFMA, OPB_WSET, OPB_WFIN = 0, 1, 3, 5
 
@@ -300,10 +306,12 @@ class _Emitter:
         return k, a, b, d
 
 
-def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, fwd_chunk: int = CHUNK):
-    """-> dict(fwd=(kind, a, b, d), bwd=(kind, a, b, d), a_list=entries of L that carry an A value, fwd_chunk).
+def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, fwd_chunk: int = CHUNK, fused_asm=None):
+    """-> dict(fwd=(kind, a, b, d), bwd=(kind, a, b, d), a_list=entries of L that carry an A value, fwd_chunk, imm).
     rhs_nonzero[i] (permuted order): rows whose load F_i may be non-zero (None = all).  fwd_chunk = ops per
-    prefetch chunk of the forward stream (8 or 16; the backward stream always uses CHUNK)."""
+    prefetch chunk of the forward stream (8 or 16; the backward stream always uses CHUNK).  fused_asm = (c0, ptr,
+    idx, w) from CholeskyPlan.entry_table: the stream then assembles A_e = c0_e + sum_t w_t x[idx_t] itself (XFMA /
+    CADD ops with the weights in `imm`), a_list comes back empty and no assembly pre-pass is needed."""
     n, nnzL = plan.n, plan.nnzL
     row_ptr, ent_col = plan.row_ptr.astype(np.int64), plan.ent_col.astype(np.int64)
     pair_ptr = plan.pair_ptr.astype(np.int64)
@@ -324,6 +332,9 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
 
     # ---------------- forward: factorisation + L y = F -----------------------------------
     NEG1, ZERO = cache_slots, cache_slots + 1
+    imm = []
+    if fused_asm is not None:
+        f_c0, f_ptr, f_idx, f_w = (np.asarray(a) for a in fused_asm)
     em = _Emitter(nnzL + 2 * n, pad_b=ZERO, chunk=fwd_chunk)
     done_chunk = np.zeros(n, np.int64)
     remaining = ndeps.copy()
@@ -348,7 +359,12 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
         e0, e1 = row_ptr[i], row_ptr[i + 1]
         for e in range(e0, e1):
             j = ent_col[e]
-            if plan.a_ent[e] >= 0:
+            if plan.a_ent[e] >= 0 and fused_asm is not None:
+                if f_c0[e] != 0.0:
+                    em.emit(OP_CADD, d=len(imm)); imm.append(float(f_c0[e]))
+                for t in range(f_ptr[e], f_ptr[e + 1]):
+                    em.emit(OP_XFMA, b=int(f_idx[t]), d=len(imm)); imm.append(float(f_w[t]))
+            elif plan.a_ent[e] >= 0:
                 em.emit(OP_FMA, a=e, b=NEG1, loads=(e,))              # acc = 0 - (-1) * A_e
             for q in range(pair_ptr[e], pair_ptr[e + 1]):
                 pa, pb = int(plan.pair_a[q]), int(plan.pair_b[q])
@@ -427,8 +443,8 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
                 heapq.heappush(eligible, (-depth[u], u))
     assert cnt == n
     bwd = emb.arrays()
-    a_list = np.nonzero(plan.a_ent >= 0)[0].astype(np.int32)
-    return {"fwd": fwd, "bwd": bwd, "a_list": a_list, "fwd_chunk": fwd_chunk}
+    a_list = np.nonzero(plan.a_ent >= 0)[0].astype(np.int32) if fused_asm is None else np.zeros(0, np.int32)
+    return {"fwd": fwd, "bwd": bwd, "a_list": a_list, "fwd_chunk": fwd_chunk, "imm": np.asarray(imm, np.float64)}
 
 
 def build_resolve_stream(plan: "CholeskyPlan", base: int):
@@ -477,7 +493,7 @@ def replay_resolve_stream(plan, stream, Lvals, invd, b_perm, base):
     return G[base:].copy()
 
 
-def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
+def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots, x=None):
     """NumPy replay of the device interpreter WITH its prefetch semantics (operands of chunk c+1 are
     read before chunk c executes); A_entries[e] = assembled A value of entry e (0 for fill).
     Returns w in the permuted dof order."""
@@ -522,6 +538,8 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots):
                         if b[t] >= 0: rc[b[t]] = l
                     elif k == OP_FINDIAG:
                         dd = np.sqrt(acc); inv = 1.0 / dd; G[d[t]] = dd; G[nnzL + b[t]] = inv; acc = 0.0
+                    elif k == OP_XFMA: acc += streams["imm"][d[t]] * x[b[t]]
+                    elif k == OP_CADD: acc += streams["imm"][d[t]]
                     elif k == OP_YSET: acc = rhs_perm[d[t]]
                     elif k == OP_FINY: G[d[t]] = acc * inv; acc = 0.0
     run(streams["fwd"], False, streams.get("fwd_chunk", CHUNK))

@@ -167,9 +167,8 @@ def main():
         elif ms.get(dom, 0) > 0:
             # FOM interpreter: per sample one 8-B operand per multiply-add of the schedule
             # (the other operand sits in LDS), L / 1/L_ii / y / w each written once, x read once
-            from bayesianinferencedl_amd.engine import ROW_CACHE_SLOTS, FWD_CHUNK
-            st = plan.op_streams(ROW_CACHE_SLOTS, ops.F[plan.perm], FWD_CHUNK)
-            nload_f = int(((st["fwd"][0] != 0) | (st["fwd"][1] >= 0)).sum())
+            st = solver._engine("field" if args.params == "field" else args.params)._streams
+            nload_f = int((st["fwd"][1] >= 0).sum())                 # ops that fetch a global operand
             nload_b = int((st["bwd"][0] == 1).sum() * 2 + (st["bwd"][0] > 1).sum())
             per_sample = 8 * (nload_f + nload_b + 2 * plan.nnzL + 4 * ops.n + pairs.xdim + pairs.n_obs)
             alg = S * per_sample

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 2
+#define FINROM_ABI_VERSION 3
 
 typedef enum {
   FINROM_OK = 0,
@@ -96,6 +96,8 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
  *            5 FINOFF l = acc*G[a]; G[d] = l; if b >= 0: rc[b] = l; acc = 0
  *            6 FINDIAG t = sqrt(acc); G[d] = t; G[nnzL+b] = inv = 1/t; acc = 0 (acc <= 0 flags the sample)
  *            7 YSET acc = rhs[d] | 8 FINY G[d] = acc*inv; acc = 0
+ *            9 XFMA acc += imm[d]*x[b] | 10 CADD acc += imm[d]   (fused affine assembly, xdim <= 16: the stream builds
+ *                  A_e = c0_e + sum_t w_t x[idx_t] itself, x sits in LDS, and there is no assembly pre-pass: n_alist = 0)
  *   backward 0 NOP | 1 WFMA acc -= G[a]*G[b] | 3 WSET acc = G[a] | 5 WFIN G[d] = acc*G[a]
  */
 typedef struct {
@@ -104,7 +106,7 @@ typedef struct {
   int32_t xdim;            /* length of one parameter vector x */
   int32_t n_obs;           /* rows of the observation operator */
   int32_t nasm;            /* entries of asm_idx / asm_w */
-  int32_t n_alist;         /* entries of L that carry a value of A */
+  int32_t n_alist;         /* entries of L that carry a value of A and are assembled by the pre-pass (0: fused stream) */
   int32_t cache_slots;     /* LDS row-cache slots the forward stream assumes (1..126): (cache_slots+2)*512 B of LDS
                               per wave decide how many interpreter waves share a CU (42 -> 7, 72 -> 4) */
   int32_t fwd_chunk;       /* ops per prefetch chunk of the forward stream: 8 or 16 */
@@ -122,6 +124,8 @@ typedef struct {
   const int32_t* obs_idx;
   const double*  obs_w;
   const int32_t* perm;     /* [n] permuted -> original dof (to return w in caller order) */
+  int32_t n_imm;           /* immediates of the XFMA / CADD ops (0 if the stream has none) */
+  const double*  imm;      /* [n_imm] */
 } finrom_fom_desc;
 
 int finrom_fom_create(const finrom_fom_desc* desc, finrom_fom_t* out);

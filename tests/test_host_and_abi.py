@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in finrom.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib.finrom_version.restype = ctypes.c_int
-    assert lib.finrom_version() == 2
+    assert lib.finrom_version() == 3
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -214,3 +214,27 @@ def test_error_model_vjp_matches_finite_differences():
         e = np.zeros(30); e[j] = eps
         fd = ((m.predict(x + e).astype(np.float64) - m.predict(x - e).astype(np.float64)) / (2 * eps) * up).sum(axis=1)
         assert np.allclose(fd, g[:, j], rtol=3e-2, atol=3e-3)
+
+
+@pytest.mark.parametrize("params", ["five", "nine"])
+def test_fused_assembly_stream_replays_to_the_same_solution(spaces, params):
+    """Short parameter vectors: the op stream assembles A_e = c0_e + sum_t w_t x[idx_t] itself (XFMA / CADD ops with
+    immediates) instead of reading the pre-pass's output; the NumPy replay with prefetch semantics must still solve A w = F."""
+    import scipy.sparse as sp
+    from bayesianinferencedl_amd.symbolic import CholeskyPlan, build_op_streams, replay_op_streams, OP_XFMA, OP_CADD
+    ops = spaces(4).operators()
+    plan = CholeskyPlan(ops.indptr, ops.indices, ops.n)
+    lift = ops.N9 if params == "nine" else ops.N9 @ ops.E59
+    W = sp.csr_matrix(ops.W_field @ sp.csr_matrix(lift))
+    tab = plan.entry_table(ops.robin_vals, W)
+    cache = 12
+    st = build_op_streams(plan, cache, None, 8, tab)
+    k = st["fwd"][0]
+    assert len(st["a_list"]) == 0 and (k == OP_XFMA).sum() == len(tab[3]) and (k == OP_CADD).sum() == (tab[0] != 0).sum()
+    assert len(st["imm"]) == (k == OP_XFMA).sum() + (k == OP_CADD).sum()
+    rng = np.random.default_rng(6)
+    x = rng.uniform(0.1, 10.0, lift.shape[1])
+    wp = replay_op_streams(plan, st, np.zeros(plan.nnzL), ops.F[plan.perm], cache, x=x)
+    w = np.empty(ops.n); w[plan.perm] = wp
+    ref = spl.spsolve(ops.csr(ops.fom_values(lift @ x)).tocsc(), ops.F)
+    assert np.linalg.norm(w - ref) < 1e-12 * np.linalg.norm(ref)
