@@ -548,8 +548,14 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
     // wants A_r itself back (the state the reference's gradients use) or the basis needs more than one wave
     const bool want_factor = (A_r == nullptr || getenv("FINROM_DEBUG_RETURN_FACTOR") != nullptr) &&
                              getenv("FINROM_NO_FUSED_CHOL") == nullptr;   // debug: A_r output then holds L
-    const int factor = (want_factor && d.NB <= 6) ? 1 : 0;            // in-register, inside the projection kernel
-    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, factor, info ? info + s0 : nullptr, st))) return rc;
+    int factor = (want_factor && d.NB <= 6) ? 1 : 0;                  // in-register, inside the projection kernel
+    // ... and when neither A_r nor B_r is wanted back (r <= 80), the two substitutions and the reduced QoI happen there
+    // as well: no packed factor in memory, no second kernel
+    if (factor && d.NB <= 5 && A_r == nullptr && B_r == nullptr && getenv("FINROM_NO_FUSED_SOLVE") == nullptr &&
+        getenv("FINROM_PROJ_LDS") == nullptr) factor = 2;
+    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, factor, info ? info + s0 : nullptr, st,
+                              w_r ? w_r + s0 * d.r : nullptr, qoi_r ? qoi_r + s0 * d.n_obs : nullptr))) return rc;
+    if (factor == 2) continue;
     int factored = factor;
     if (want_factor && d.NB > 6) {                                     // wider bases: blocked MFMA Cholesky kernel
       if ((rc = launch_rom_chol_blocked(d, (double*)h->Ar.p, Sc, info ? info + s0 : nullptr, st))) return rc;

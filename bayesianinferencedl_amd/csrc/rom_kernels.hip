@@ -14,141 +14,9 @@
 // upper block triangle of A_r (NB(NB+1)/2 tiles of 16x16).  Bound: fp64 MFMA issue.
 #include "finrom_internal.h"
 
+#include "rom_proj_device.h"
+
 namespace finrom {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-// One k-step = 4 rows of psi.  Rows are sorted by their number of terms, so the k-steps form a
-// few PHASES with a constant term count nt (<= 4): slot t of k-step ks is 4 padded r-vectors at
-//   tv[((slot0 + (ks - ks0) * nt + t) * 4 + q) * rp + col],   theta index pidx[(slot) * 4 + q],
-// i.e. every address is a function of the loop counter (no dependent index loads), and the raw
-// table values of k-step ks+1 are fetched into registers while the MFMAs of k-step ks issue.
-constexpr int ROM_MAX_NT = 4;
-
-template <int NB>
-__device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const int* __restrict__ pidx, int slot, int nt,
-                                           int rp, int q, int c, double (&raw)[ROM_MAX_NT][NB], int (&pi)[ROM_MAX_NT]) {
-#pragma unroll
-  for (int t = 0; t < ROM_MAX_NT; ++t) {
-    if (t < nt) {                                  // wave-uniform
-      const int row = (slot + t) * 4 + q;
-      pi[t] = pidx[row];
-      const double* src = tv + (int64_t)row * rp + c;
-#pragma unroll
-      for (int b = 0; b < NB; ++b) raw[t][b] = src[16 * b];
-    }
-  }
-}
-
-// The accumulators MUST live in architectural VGPRs: measured on gfx950 (tools/mfma_f64_variants.hip),
-// v_mfma_f64_16x16x4_f64 issues every 64 cycles (77 TFLOP/s chip-wide) with VGPR accumulators but only
-// every ~131 cycles (38 TFLOP/s) with AGPR accumulators, which is what hipcc picks for the builtin in a
-// kernel of this size.  Hence inline asm with "+v" constraints; hipcc pads nothing around inline asm, so
-// the VALU->MFMA operand hazard is covered by the s_nop in front of each k-step's MFMA group.
-template <int NB, int NW, int W>
-__device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
-  // Bases wider than 128 spill accumulators; spill code next to inline asm is not hazard-safe
-  // (the compiler cannot see that the asm is an MFMA), so those sizes use the compiler-managed builtin.
-  constexpr bool kAsm = NB <= 10 || NW >= 8;   // (NB, NW) whose accumulators fit architectural VGPRs without spills
-  int idx = 0, mine = 0;
-#pragma unroll
-  for (int ti = 0; ti < NB; ++ti)
-#pragma unroll
-    for (int tj = ti; tj < NB; ++tj) {
-      if (idx % NW == W) {
-        // the wait states for "VALU wrote an operand -> MFMA reads it" sit INSIDE the asm statement: a
-        // separate s_nop statement can be scheduled away from the MFMA it is meant to protect
-        if constexpr (kAsm) asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[mine]) : "v"(v[ti]), "v"(v[tj]));
-        else acc[mine] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[mine], 0, 0, 0);
-        ++mine;
-      }
-      ++idx;
-    }
-}
-
-// Wait for the in-flight inline-asm MFMAs before the compiler-scheduled code reads their results: the
-// wait carries every accumulator as an in/out operand, so no reader can be scheduled above it.
-template <int N>
-__device__ __forceinline__ void mfma_drain(d4 (&acc)[N]) {
-#pragma unroll
-  for (int t = 0; t < N; ++t) {
-    if (t == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[t]));
-    else asm volatile("" : "+v"(acc[t]));
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// In-register blocked Cholesky A_r = U^T U on the MFMA accumulator tiles (one wave, NW == 1).
-// Tile (ti <= tj) holds rows 16ti.., columns 16tj.. in the C/D layout (lane: q = row&3 group, c = column;
-// register g: row q + 4g).  Block row kb: 16 right-looking steps (pivot, scale, rank-1 update) with lane
-// shuffles inside the block row; the update of the trailing tiles is 4 MFMAs per tile whose operands ARE
-// the freshly computed registers of U (A[i][k] = U[k][i] lives exactly where the C/D layout put it).
-// ---------------------------------------------------------------------------------------
-template <int NB>
-__device__ __forceinline__ int tile_index(int ti, int tj) { return ti * NB - (ti * (ti - 1)) / 2 + (tj - ti); }
-
-template <int NB>
-__device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, int c, int r) {
-  int bad = 0;
-  // padding rows/columns (>= r) of psi^T psi are zero: give them a unit diagonal
-#pragma unroll
-  for (int t = 0; t < NB; ++t)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      if (q + 4 * g == c && 16 * t + c >= r) acc[tile_index<NB>(t, t)][g] = 1.0;
-#pragma unroll
-  for (int kb = 0; kb < NB; ++kb) {
-    const int dg = tile_index<NB>(kb, kb);
-#pragma unroll
-    for (int st = 0; st < 16; ++st) {
-      const int qs = st & 3, gs = st >> 2;
-      const double piv = __shfl(acc[dg][gs], qs * 16 + st);
-      bad |= !(piv > 0.0);
-      double rinv = __builtin_amdgcn_rsq(piv);                 // 1/sqrt: hardware estimate + Newton steps
-#pragma unroll
-      for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
-      const double sc = (q == qs) ? rinv : 1.0;
-#pragma unroll
-      for (int tj = kb; tj < NB; ++tj) acc[dg + (tj - kb)][gs] *= sc;     // row st of U is final
-      double m[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const double v = __shfl(acc[dg][gs], qs * 16 + ((q + 4 * g) & 15));
-        m[g] = (q + 4 * g > st) ? v : 0.0;                                // only rows below the pivot row
-      }
-#pragma unroll
-      for (int tj = kb; tj < NB; ++tj) {
-        const double rv = __shfl(acc[dg + (tj - kb)][gs], qs * 16 + c);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[dg + (tj - kb)][g] = fma(-m[g], rv, acc[dg + (tj - kb)][g]);
-      }
-    }
-    // trailing update: T(ti,tj) -= U(kb,ti)^T U(kb,tj)
-    if (kb + 1 < NB) {
-      // operands are copied out of the accumulator tuples into plain 64-bit registers first (a sub-register
-      // of a 256-bit inline-asm tuple is not guaranteed to be a legal, even-aligned MFMA source); the minus sign
-      // of the update rides on the instruction's source-A negate modifier
-      double pos[NB][4];
-#pragma unroll
-      for (int ti = kb + 1; ti < NB; ++ti)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pos[ti][g] = acc[dg + (ti - kb)][g];
-      // k-step g outermost: consecutive MFMAs hit different tiles; the drain between k-steps covers the
-      // MFMA -> same-accumulator MFMA hazard that hipcc cannot pad around inline asm
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int ti = kb + 1; ti < NB; ++ti)
-#pragma unroll
-          for (int tj = ti; tj < NB; ++tj)
-            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]"
-                         : "+v"(acc[tile_index<NB>(ti, tj)]) : "v"(pos[ti][g]), "v"(pos[tj][g]));
-        mfma_drain(acc);
-      }
-    }
-  }
-  return bad;
-}
 
 // ---------------------------------------------------------------------------------------
 // Blocked Cholesky for bases that need more than one projection wave (96 < r <= 208): one wave per sample,
@@ -263,157 +131,11 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
   return 0;
 }
 
-template <int NB, int NW, int W>
-__device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
-                                              double* __restrict__ Ar, double* __restrict__ Br, int factor,
-                                              int* __restrict__ info) {
-  constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
-  const int q = lane >> 4, c = lane & 15;
-  d4 acc[NTL];
-#pragma unroll
-  for (int t = 0; t < NTL; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-
-  // ONE copy of the MFMA group for all phases (runtime term count): several unrolled copies make hipcc
-  // spill the inline-asm accumulators around every copy
-  {
-    double raw[ROM_MAX_NT][NB];
-    int pi[ROM_MAX_NT];
-    int ph = 0;
-    while (ph < p.n_phases && p.phase_ks0[ph] >= p.phase_ks1[ph]) ++ph;
-    if (ph < p.n_phases) load_kstep<NB>(p.tv, p.pidx, p.phase_slot0[ph], p.phase_nt[ph], p.rp, q, c, raw, pi);
-#pragma unroll 1
-    for (; ph < p.n_phases; ++ph) {
-      const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph], nt = p.phase_nt[ph];
-      // what follows the last k-step of this phase: the first k-step of the next non-empty phase (or padding)
-      int nph = ph + 1;
-      while (nph < p.n_phases && p.phase_ks0[nph] >= p.phase_ks1[nph]) ++nph;
-      const int next_slot = nph < p.n_phases ? p.phase_slot0[nph] : slot0 + (ks1 - ks0) * nt;
-      const int next_nt = nph < p.n_phases ? p.phase_nt[nph] : 1;
-#pragma unroll 1
-      for (int ks = ks0; ks < ks1; ++ks) {
-        double v[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) v[b] = 0.0;
-#pragma unroll
-        for (int t = 0; t < ROM_MAX_NT; ++t) {
-          if (t < nt) {
-            const double thp = thw[pi[t]];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) v[b] = fma(thp, raw[t][b], v[b]);
-          }
-        }
-        // raw is dead now: fetch the next k-step into it; the loads fly while this k-step's MFMAs issue
-        // (the table is padded by one k-step of zeros, so the last prefetch stays inside it)
-        const bool last = ks + 1 == ks1;
-        load_kstep<NB>(p.tv, p.pidx, last ? next_slot : slot0 + (ks + 1 - ks0) * nt, last ? next_nt : nt, p.rp, q, c, raw, pi);
-        mfma_tiles<NB, NW, W>(v, acc);
-      }
-    }
-  }
-
-  // let the last MFMAs retire before their results are read (no hazard padding around inline asm)
-  mfma_drain(acc);
-  if constexpr (NW == 1 && NB <= 6) {
-    if (factor) {      // A_r = U^T U in registers; what is written below is then U^T (= L, packed by columns)
-      const int bad = chol_tiles<NB>(acc, q, c, p.r);
-      if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
-    }
-  }
-  // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15].
-  // A_r is symmetric: tile (ti <= tj) element (row, col) is written as the LOWER element
-  // (i = col, k = row) of the packed column-major lower triangle the solve kernel reads.
-  const int R = p.rp;
-  double* A = Ar + s * (int64_t)(R * (R + 1) / 2);
-  int idx = 0, mine = 0;
-#pragma unroll
-  for (int ti = 0; ti < NB; ++ti)
-#pragma unroll
-    for (int tj = ti; tj < NB; ++tj) {
-      if (idx % NW == W) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = 16 * ti + q + 4 * g, col = 16 * tj + c;
-          if (ti != tj || col >= row) A[row * R - (row * (row - 1)) / 2 + col - row] = acc[mine][g];
-        }
-        ++mine;
-      }
-      ++idx;
-    }
-
-  // B_r = psi^T F (rom :297): F is non-zero on the root nodes only; their rows of psi are rebuilt
-  // here (a handful of k-steps, VALU only) and reduced over the 4 row-groups by lane shuffles.
-  if (W == 0) {
-    double bacc[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
-    for (int ks = 0; ks < p.rhs_nk; ++ks) {
-      double v[NB];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) v[b] = 0.0;
-      for (int t = 0; t < p.rhs_nt; ++t) {
-        const int row = (ks * p.rhs_nt + t) * 4 + q;
-        const double thp = thw[p.rhs_pidx[row]];
-        const double* src = p.rhs_tv + (int64_t)row * p.rp + c;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) v[b] = fma(thp, src[16 * b], v[b]);
-      }
-      const double fk = p.rhs_f[ks * 4 + q];
-#pragma unroll
-      for (int b = 0; b < NB; ++b) bacc[b] = fma(v[b], fk, bacc[b]);
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      double x = bacc[b];
-      x += __shfl_xor(x, 16);
-      x += __shfl_xor(x, 32);
-      if (q == 0) Br[s * p.rp + 16 * b + c] = x;
-    }
-  }
-}
-
-// NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
-// workgroup is 4 waves = 4/NW samples.
-// NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
-// workgroup is max(4, NW) waves = max(4, NW)/NW samples.
 template <int NB, int NW>
 __global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
-                                                       int* __restrict__ info) {
-  constexpr int WPB = NW > 4 ? NW : 4;
-  __shared__ double th[WPB][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  trace_begin(p.trace, blockIdx.x);
-  const int64_t s = (int64_t)blockIdx.x * (WPB / NW) + wave / NW;
-  if (s >= S) return;                       // no block-wide barrier below
-  if (lane == 0) th[wave][0] = 1.0;
-  if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
-  __builtin_amdgcn_wave_barrier();
-  const double* thw = th[wave];
-  if constexpr (NW == 1) {
-    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info);
-  } else if constexpr (NW == 2) {
-    if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br, factor, info);
-    else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br, factor, info);
-  } else if constexpr (NW == 4) {
-    switch (wave % 4) {
-      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info); break;
-      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info); break;
-    }
-  } else {
-    switch (wave % 8) {
-      case 0: rom_proj_body<NB, 8, 0>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 1: rom_proj_body<NB, 8, 1>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 2: rom_proj_body<NB, 8, 2>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 3: rom_proj_body<NB, 8, 3>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 4: rom_proj_body<NB, 8, 4>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 5: rom_proj_body<NB, 8, 5>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 6: rom_proj_body<NB, 8, 6>(p, thw, s, lane, Ar, Br, factor, info); break;
-      default: rom_proj_body<NB, 8, 7>(p, thw, s, lane, Ar, Br, factor, info); break;
-    }
-  }
-  trace_end(p.trace, blockIdx.x);
+                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r) {
+  rom_proj_entry<NB, NW>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -571,7 +293,8 @@ static int launch_proj_lds(const RomDev& p, const double* theta, int64_t S, doub
 }
 
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
-                    hipStream_t st) {
+                    hipStream_t st, double* w_r, double* qoi_r) {
+  // factor: 0 = write A_r, 1 = write its Cholesky factor (NB <= 6), 2 = also solve and write only w_r / qoi_r (NB <= 5)
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_PROJ, st);
   // The LDS-staged variant shares each table fetch among the 4 waves of a workgroup; measured on MI355X it
@@ -590,9 +313,10 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
 #define FR_CASE(N, W)                                                                              \
   case N: { constexpr int wpb = W > 4 ? W : 4; constexpr int spb = wpb / W;                        \
             hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + spb - 1) / spb)),     \
-                               dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info); } break;
+                               dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r); } break;
   switch (p.NB) {
-    FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(5, 1) FR_CASE(6, 1)
+    FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(6, 1)
+    case 5: return launch_rom_proj_r80(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);    // own translation unit (-O2)
     FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
     FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 4)   // 8 waves/sample measured slower (each wave rebuilds the slab)
     default:
