@@ -132,6 +132,16 @@ def main():
         L.finrom_set_overlap(1)
         L.finrom_profile_enable(0)
         serial_ms = {k: round(v[1] / v[0], 4) for k, v in _ffi.profile_read().items() if v[0]}
+    # context only: the same step fed from / returned to HOST memory through the library's own copies (the NumPy-facing
+    # boundary; parameters in, QoI pairs + errors + w_r + theta + info out), i.e. the PCIe-inclusive rate.  Never `value`.
+    host_io = None
+    if not args.no_profile and world == 1:
+        Xh = X.cpu().numpy()
+        pairs.solve_pairs(Xh)
+        t0 = time.perf_counter()
+        pairs.solve_pairs(Xh)
+        host_io = S / (time.perf_counter() - t0)
+        del Xh
     L.finrom_profile_reset()
     L.finrom_profile_enable(0 if args.no_profile else 1)
     t0 = time.perf_counter()
@@ -198,6 +208,7 @@ def main():
             "cpu_baseline": cpu,
             "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0},
             "kernels_serial_ms": serial_ms,
+            "host_io_pairs_per_s": host_io,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
