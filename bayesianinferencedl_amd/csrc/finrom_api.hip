@@ -648,10 +648,8 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     if ((rc = rom->theta.reserve((size_t)S * rom->d.P * sizeof(double)))) return rc;
     theta = (double*)rom->theta.p;
   }
-  // Two streams pay off when a projection wave owns a whole sample (r <= 96): those workgroups and the interpreter
-  // waves fit a SIMD together (2 x 192 + 2 x 56 registers).  The 4-waves-per-sample kernels of wider bases lose
-  // more beside the interpreter than the overlap returns (measured: r = 120 and r = 200), so they run in turn.
-  const bool overlap = g_overlap && rom->d.NB <= 6 && getenv("FINROM_NO_OVERLAP") == nullptr;   // serial mode: per-kernel profiling
+  // the two halves run on two streams (FINROM_NO_OVERLAP / finrom_set_overlap(0): in turn, for per-kernel profiling)
+  const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr;
   hipStream_t side = overlap ? rom->side : st;
   const bool tracing = trace_prefix() != nullptr;
   if (tracing) {

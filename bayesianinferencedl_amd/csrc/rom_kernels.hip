@@ -318,7 +318,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
     FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(6, 1)
     case 5: return launch_rom_proj_r80(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);    // own translation unit (-O2)
     FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
-    FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 4)   // 8 waves/sample measured slower (each wave rebuilds the slab)
+    FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 8)   // r > 192: 8 waves per sample so that a wave's tiles fit architectural VGPRs
     default:
       set_error("rom_proj: basis size " + std::to_string(p.r) + " > 208 not supported");
       return FINROM_ERR_UNSUPPORTED;

@@ -30,6 +30,24 @@ __device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const 
   }
 }
 
+// NW > 1 waves share a sample: wave W builds only the blocks W, W + NW, ... of the slab (own index j <-> block W + j NW)
+template <int NB, int NW, int W>
+__device__ __forceinline__ void load_kstep_own(const double* __restrict__ tv, const int* __restrict__ pidx, int slot, int nt,
+                                               int rp, int q, int c, double (&raw)[ROM_MAX_NT][(NB - W + NW - 1) / NW],
+                                               int (&pi)[ROM_MAX_NT]) {
+  constexpr int NOWN = (NB - W + NW - 1) / NW;
+#pragma unroll
+  for (int t = 0; t < ROM_MAX_NT; ++t) {
+    if (t < nt) {                                  // wave-uniform
+      const int row = (slot + t) * 4 + q;
+      pi[t] = pidx[row];
+      const double* src = tv + (int64_t)row * rp + c;
+#pragma unroll
+      for (int j = 0; j < NOWN; ++j) raw[t][j] = src[16 * (W + j * NW)];
+    }
+  }
+}
+
 // The accumulators MUST live in architectural VGPRs: measured on gfx950 (tools/mfma_f64_variants.hip),
 // v_mfma_f64_16x16x4_f64 issues every 64 cycles (77 TFLOP/s chip-wide) with VGPR accumulators but only
 // every ~131 cycles (38 TFLOP/s) with AGPR accumulators, which is what hipcc picks for the builtin in a
@@ -39,7 +57,7 @@ template <int NB, int NW, int W>
 __device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
   // Bases wider than 128 spill accumulators; spill code next to inline asm is not hazard-safe
   // (the compiler cannot see that the asm is an MFMA), so those sizes use the compiler-managed builtin.
-  constexpr bool kAsm = NB <= 10 || NW >= 8;   // (NB, NW) whose accumulators fit architectural VGPRs without spills
+  constexpr bool kAsm = true;      // every instantiated (NB, NW) keeps its tiles in architectural VGPRs
   int idx = 0, mine = 0;
 #pragma unroll
   for (int ti = 0; ti < NB; ++ti)
@@ -202,13 +220,58 @@ template <int NB, int NW, int W>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                               int* __restrict__ info, double* __restrict__ w_r = nullptr,
-                                              double* __restrict__ qoi_r = nullptr) {
+                                              double* __restrict__ qoi_r = nullptr, double* slab = nullptr) {
   constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
   const int q = lane >> 4, c = lane & 15;
   d4 acc[NTL];
 #pragma unroll
   for (int t = 0; t < NTL; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 
+  if constexpr (NW > 1) {
+    // The NW waves of a sample (= the workgroup) share the slab through LDS: wave W builds its own blocks from the tables
+    // (1/NW of the loads and multiply-adds: stand-alone, every wave rebuilding the whole slab saturates the CU's L1 path),
+    // writes them to slab[ks & 1], and after ONE barrier per k-step every wave reads the whole slab back for its tiles.
+    // Double-buffered: a wave can only be one barrier ahead, so the buffer it overwrites is no longer being read.
+    constexpr int NOWN = (NB - W + NW - 1) / NW;
+    double raw[ROM_MAX_NT][NOWN];
+    int pi[ROM_MAX_NT];
+    int ph = 0, par = 0;
+    while (ph < p.n_phases && p.phase_ks0[ph] >= p.phase_ks1[ph]) ++ph;
+    if (ph < p.n_phases) load_kstep_own<NB, NW, W>(p.tv, p.pidx, p.phase_slot0[ph], p.phase_nt[ph], p.rp, q, c, raw, pi);
+#pragma unroll 1
+    for (; ph < p.n_phases; ++ph) {
+      const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph], nt = p.phase_nt[ph];
+      int nph = ph + 1;
+      while (nph < p.n_phases && p.phase_ks0[nph] >= p.phase_ks1[nph]) ++nph;
+      const int next_slot = nph < p.n_phases ? p.phase_slot0[nph] : slot0 + (ks1 - ks0) * nt;
+      const int next_nt = nph < p.n_phases ? p.phase_nt[nph] : 1;
+#pragma unroll 1
+      for (int ks = ks0; ks < ks1; ++ks) {
+        double own[NOWN];
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) own[j] = 0.0;
+#pragma unroll
+        for (int t = 0; t < ROM_MAX_NT; ++t) {
+          if (t < nt) {
+            const double thp = thw[pi[t]];
+#pragma unroll
+            for (int j = 0; j < NOWN; ++j) own[j] = fma(thp, raw[t][j], own[j]);
+          }
+        }
+        double* buf = slab + par * (NB * 64);
+        par ^= 1;
+#pragma unroll
+        for (int j = 0; j < NOWN; ++j) buf[(W + j * NW) * 64 + lane] = own[j];
+        const bool last = ks + 1 == ks1;
+        load_kstep_own<NB, NW, W>(p.tv, p.pidx, last ? next_slot : slot0 + (ks + 1 - ks0) * nt, last ? next_nt : nt, p.rp, q, c, raw, pi);
+        __syncthreads();
+        double v[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) v[b] = buf[b * 64 + lane];
+        mfma_tiles<NB, NW, W>(v, acc);
+      }
+    }
+  } else
   // ONE copy of the MFMA group for all phases (runtime term count): several unrolled copies make hipcc
   // spill the inline-asm accumulators around every copy
   {
@@ -345,7 +408,10 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                        int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r) {
   constexpr int WPB = NW > 4 ? NW : 4;
+  static_assert(NW == 1 || NW >= 4, "a workgroup is one sample when its waves share the slab (uniform early exit, barriers)");
   __shared__ double th[WPB][32];
+  __shared__ double slab_lds[NW > 1 ? 2 * NB * 64 : 1];
+  double* slab = slab_lds;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   trace_begin(p.trace, blockIdx.x);
   const int64_t s = (int64_t)blockIdx.x * (WPB / NW) + wave / NW;
@@ -357,25 +423,25 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
   if constexpr (NW == 1) {
     rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r);
   } else if constexpr (NW == 2) {
-    if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br, factor, info);
-    else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br, factor, info);
+    if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab);
+    else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab);
   } else if constexpr (NW == 4) {
     switch (wave % 4) {
-      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info); break;
-      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
     }
   } else {
     switch (wave % 8) {
-      case 0: rom_proj_body<NB, 8, 0>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 1: rom_proj_body<NB, 8, 1>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 2: rom_proj_body<NB, 8, 2>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 3: rom_proj_body<NB, 8, 3>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 4: rom_proj_body<NB, 8, 4>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 5: rom_proj_body<NB, 8, 5>(p, thw, s, lane, Ar, Br, factor, info); break;
-      case 6: rom_proj_body<NB, 8, 6>(p, thw, s, lane, Ar, Br, factor, info); break;
-      default: rom_proj_body<NB, 8, 7>(p, thw, s, lane, Ar, Br, factor, info); break;
+      case 0: rom_proj_body<NB, 8, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 1: rom_proj_body<NB, 8, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 2: rom_proj_body<NB, 8, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 3: rom_proj_body<NB, 8, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 4: rom_proj_body<NB, 8, 4>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 5: rom_proj_body<NB, 8, 5>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 6: rom_proj_body<NB, 8, 6>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      default: rom_proj_body<NB, 8, 7>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
     }
   }
   trace_end(p.trace, blockIdx.x);
