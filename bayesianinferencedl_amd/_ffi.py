@@ -125,13 +125,28 @@ def f64(a):
 
 
 class DeviceBuffer:
-    """Device allocation owned by Python (finrom_malloc / finrom_free)."""
+    """Device allocation owned by Python (finrom_malloc / finrom_free).  Small buffers (<= 16 MiB, the scalar call surface
+    and modest batches) are recycled through a per-process free list: hipMalloc / hipFree cost more than the kernels of
+    a one-sample call (the MAP / HMC call pattern, SURVEY configs[4])."""
+
+    _POOL_MAX_EACH = 16 << 20
+    _POOL_MAX_TOTAL = 256 << 20
+    _pool = {}            # capacity -> [device pointers]
+    _pool_bytes = 0
 
     def __init__(self, nbytes: int):
         self.nbytes = int(nbytes)
+        cap = max(self.nbytes, 8)
+        if cap <= self._POOL_MAX_EACH:
+            cap = 1 << (cap - 1).bit_length()                 # size classes: powers of two
+            free = DeviceBuffer._pool.get(cap)
+            if free:
+                self.ptr, self._cap = free.pop(), cap
+                DeviceBuffer._pool_bytes -= cap
+                return
         p = C.c_void_p()
-        check(lib().finrom_malloc(C.byref(p), max(self.nbytes, 8)), "finrom_malloc")
-        self.ptr = p.value
+        check(lib().finrom_malloc(C.byref(p), cap), "finrom_malloc")
+        self.ptr, self._cap = p.value, cap
 
     @classmethod
     def from_numpy(cls, a, stream=None):
@@ -151,7 +166,13 @@ class DeviceBuffer:
 
     def free(self):
         if getattr(self, "ptr", None):
-            lib().finrom_free(self.ptr)
+            cap = self._cap
+            if cap <= self._POOL_MAX_EACH and DeviceBuffer._pool_bytes + cap <= self._POOL_MAX_TOTAL:
+                # every user of this buffer was a library call that synchronised when results were copied back
+                DeviceBuffer._pool.setdefault(cap, []).append(self.ptr)
+                DeviceBuffer._pool_bytes += cap
+            else:
+                lib().finrom_free(self.ptr)
             self.ptr = None
 
     def __del__(self):
