@@ -11,13 +11,13 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfinrom_hip.so")
-SOURCES = ["finrom_api.hip", "fom_kernels.hip", "rom_kernels.hip", "rom_proj_r80.hip", "util_kernels.hip"]
+SOURCES = ["finrom_api.hip", "fom_kernels.hip", "rom_kernels.hip", "rom_proj_single.hip", "util_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "finrom_internal.h"), os.path.join(CSRC, "rom_proj_device.h"), os.path.join(ROOT, "include", "finrom.h")]
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-# rom_proj_r80.hip is built at -O2: at -O3 hipcc's extra passes inflate the register pressure of the r = 80 projection kernel
+# rom_proj_single.hip is built at -O2: at -O3 hipcc's extra passes inflate the register pressure of the r = 80 projection kernel
 # (chol_tiles + solve_tiles around inline-asm MFMA tuples) from 188 VGPRs to 256 + 388 B of scratch, and the kernel
 # must stay at <= 192 to share SIMDs with the FOM interpreter.  The MFMA main loop is inline asm either way.
-OPT = {"rom_proj_r80.hip": "-O2"}
+OPT = {"rom_proj_single.hip": "-O2"}
 
 
 def _hipcc():

@@ -132,8 +132,8 @@ int launch_rom_grad(const RomDev& p, const double* Ar, const double* Br, int64_t
 int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, hipStream_t st);
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st,
                     double* w_r = nullptr, double* qoi_r = nullptr);
-int launch_rom_proj_r80(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
-                        hipStream_t st, double* w_r, double* qoi_r);
+int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                           hipStream_t st, double* w_r, double* qoi_r);
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r,
                      double* qoi_r, double* Ar_out, double* Br_out, int* info, int factored, hipStream_t st);
 

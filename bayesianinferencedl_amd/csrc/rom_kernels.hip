@@ -315,8 +315,9 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
             hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + spb - 1) / spb)),     \
                                dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r); } break;
   switch (p.NB) {
-    FR_CASE(1, 1) FR_CASE(2, 1) FR_CASE(3, 1) FR_CASE(4, 1) FR_CASE(6, 1)
-    case 5: return launch_rom_proj_r80(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);    // own translation unit (-O2)
+    case 1: case 2: case 3: case 4: case 5:      // own translation unit (-O2)
+      return launch_rom_proj_single(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+    FR_CASE(6, 1)
     FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
     FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 8)   // r > 192: 8 waves per sample so that a wave's tiles fit architectural VGPRs
     default:

@@ -1,5 +1,5 @@
 // Device code of the projection kernels (psi build + psi^T psi on fp64 MFMA, in-register Cholesky and substitutions),
-// shared by rom_kernels.hip and rom_proj_r80.hip: the r = 80 instantiation lives in its own translation unit because it
+// shared by rom_kernels.hip and rom_proj_single.hip: the r = 80 instantiation lives in its own translation unit because it
 // is compiled at -O2 (register budget, see _build.py), everything else at -O3.
 #pragma once
 #include "finrom_internal.h"

@@ -1,0 +1,30 @@
+// The single-wave projection kernels (r <= 80: one wave owns a sample, factorisation + substitutions in registers) in their
+// own translation unit, built at -O2 (see _build.py): hipcc's -O3 inflates their register use (r = 80: 188 -> 256 VGPRs +
+// scratch), and they must stay small enough to share a SIMD with the FOM interpreter's waves: 2 x 192 registers of the
+// r = 80 kernel and 2 x 56 of the interpreter fill a SIMD's 512 exactly.
+#include "rom_proj_device.h"
+
+namespace finrom {
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void rom_proj_single_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+                                                                 double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                                                 int* __restrict__ info, double* __restrict__ w_r,
+                                                                 double* __restrict__ qoi_r) {
+  rom_proj_entry<NB, 1>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r);
+}
+
+int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                           hipStream_t st, double* w_r, double* qoi_r) {
+  const dim3 grid((unsigned)((S + 3) / 4)), block(256);
+  switch (p.NB) {
+#define FR_ONE(N) case N: hipLaunchKernelGGL(rom_proj_single_kernel<N>, grid, block, 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r); break;
+    FR_ONE(1) FR_ONE(2) FR_ONE(3) FR_ONE(4) FR_ONE(5)
+#undef FR_ONE
+    default: set_error("rom_proj_single: basis size > 80"); return FINROM_ERR_UNSUPPORTED;
+  }
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace finrom
