@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--params", default="five", choices=["five", "nine", "field"])
     ap.add_argument("--cpu-samples", type=int, default=2000, help="oracle samples for cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the extra (untimed) host-buffer pass")
     return ap.parse_args()
 
 
@@ -135,7 +136,7 @@ def main():
     # context only: the same step fed from / returned to HOST memory through the library's own copies (the NumPy-facing
     # boundary; parameters in, QoI pairs + errors + w_r + theta + info out), i.e. the PCIe-inclusive rate.  Never `value`.
     host_io = None
-    if not args.no_profile and world == 1:
+    if not args.no_profile and not args.no_host_io and world == 1:
         Xh = X.cpu().numpy()
         pairs.solve_pairs(Xh)
         t0 = time.perf_counter()

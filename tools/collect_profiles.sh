@@ -8,7 +8,7 @@ tag=${1:-run}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-B="bench.py --steps 3 --warmup 1 --cpu-samples 0"
+B="bench.py --steps 3 --warmup 1 --cpu-samples 0 --no-host-io"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/overlapped -o run -- python $B > $out/bench_overlapped.log 2>&1 || exit 1
 export FINROM_NO_OVERLAP=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -o run -- python $B > $out/bench_serial.log 2>&1 || exit 1

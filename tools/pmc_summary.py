@@ -27,7 +27,7 @@ summary = {"workload_key": key,
                    "as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE exact).",
            "raw": raw, "hbm_bytes_per_launch": {}, "l2_hit_rate": {}, "mfma_busy_frac": {}}
 slot_of = {"fom_vm_kernel": "fom_chol_solve", "fom_assemble_kernel": "fom_assemble", "rom_proj_kernel": "rom_proj_mfma",
-           "rom_proj_lds_kernel": "rom_proj_mfma", "rom_proj_kernel_r80": "rom_proj_mfma", "rom_solve_kernel": "rom_reduced_solve", "subfin_avg_kernel": "subfin_avg",
+           "rom_proj_lds_kernel": "rom_proj_mfma", "rom_proj_kernel_r80": "rom_proj_mfma", "rom_proj_single_kernel": "rom_proj_mfma", "rom_solve_kernel": "rom_reduced_solve", "subfin_avg_kernel": "subfin_avg",
            "pack_kernel": "pack"}
 for k, c in raw.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
