@@ -49,8 +49,8 @@ class AffineROMFin:
         self.dl_model = err_model
         self.data = None
         self.psi = None
-        self._A_r = None
-        self._B_r = None
+        self._state = None                                      # (A_r, B_r) of the last scalar solve, computed on demand
+        self._theta = None
         robin_phi = ops.csr(ops.robin_vals) @ self.phi
         terms = [(0, robin_phi)] + [(i + 1, self.dA_dsigmak_phi[i]) for i in range(9)]
         self._rom = RomEngine(self.n, self.n_r, 9, terms, ops.F, self.B_obs_phi)
@@ -59,6 +59,23 @@ class AffineROMFin:
         self._fom = None
         self._grad_ready = False
         self._psi_tables = [robin_phi] + [self.dA_dsigmak_phi[i] for i in range(9)]
+
+    # The reference leaves _A_r / _B_r behind after forward_nine_param_reduced (:296-297) for its gradient methods; the
+    # gradients here recompute what they need on the device, so the dense state is only materialised when somebody reads it
+    # (one extra library call with the A_r / B_r outputs requested).
+    def _reduced_state(self):
+        if self._state is None and self._theta is not None:
+            res = self._rom.solve(self._theta[None, :], want_state=True)
+            self._state = (res["A_r"][0], res["B_r"][0])
+        return self._state or (None, None)
+
+    @property
+    def _A_r(self):
+        return self._reduced_state()[0]
+
+    @property
+    def _B_r(self):
+        return self._reduced_state()[1]
 
     @property
     def dA_dsigmak(self):
@@ -124,12 +141,11 @@ class AffineROMFin:
 
     def forward_nine_param_reduced(self, k_s):
         t_i = time.time()
-        res = self._rom.solve(np.asarray(k_s, dtype=np.float64)[None, :], want_state=True)
+        res = self._rom.solve(np.asarray(k_s, dtype=np.float64)[None, :])
         self.fwd_time += (time.time() - t_i)
         if res["info"][0]:
             raise np.linalg.LinAlgError("reduced operator not positive definite")
-        self._A_r, self._B_r = res["A_r"][0], res["B_r"][0]     # state the gradients use (:342-343)
-        self._theta = np.asarray(k_s, dtype=np.float64).copy()
+        self._theta, self._state = np.asarray(k_s, dtype=np.float64).copy(), None
         w_r = res["w_r"][0]
         self._last = (w_r.copy(), res["qoi_r"][0].copy())
         return w_r

@@ -132,6 +132,9 @@ def test_scalar_call_surface(problems, spaces):
     assert rel(x.vector()[:], fo.forward(k)) < TOL
     assert rel(qoi, fo.qoi_operator(fo.forward(k))) < TOL
     assert rel(qoi_r, ro.qoi_reduced(ro.forward_reduced(k))) < TOL
+    # the dense reduced state the reference leaves behind (:296-297) is materialised on demand
+    _, A_r_o, B_r_o, _ = ro.forward_nine_param_reduced(ro.subfin_avg_op(k), True)
+    assert rel(solver_r._A_r, A_r_o) < 1e-12 and rel(solver_r._B_r[None, :], B_r_o[None, :]) < 1e-12
     assert rel(solver.subfin_avg_op(z), prob.S @ k) < 1e-13
     assert rel(solver_r.forward(z).vector()[:], ro.forward(k)) < TOL
     k5 = rng.uniform(0.1, 1.0, 5)
