@@ -155,10 +155,15 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   if (p.debug_phases & 1) {
     const int* __restrict__ A = fA; const int* __restrict__ KB = fKB; const int* __restrict__ D = fD;
     double bufA[FCH], bufB[FCH];
-#define VM_EXEC_F(buf, c)                                                     \
-  int kbv[FCH], dv[FCH];   /* descriptors of the whole chunk: scalar loads issued together */ \
-  _Pragma("unroll") for (int u = 0; u < FCH; ++u) { kbv[u] = KB[(c) * FCH + u]; dv[u] = D[(c) * FCH + u]; } \
+#define VM_STEP(buf, nxt, c)   /* execute chunk c from buf while the operands of chunk c+1 fly into nxt */ \
+  /* ONE batch of scalar loads per step (descriptors of chunk c, load offsets of chunk c+1): a single scalar-memory */ \
+  /* round trip instead of two -- the only latency a lone wave (one-sample calls) cannot hide */ \
+  int kbv[FCH], dv[FCH], an[FCH];                                             \
+  _Pragma("unroll") for (int u = 0; u < FCH; ++u) {                           \
+    kbv[u] = KB[(c) * FCH + u]; dv[u] = D[(c) * FCH + u]; an[u] = A[((c) + 1) * FCH + u]; \
+  }                                                                           \
   const int msk = fM[c];                                                      \
+  _Pragma("unroll") for (int u = 0; u < FCH; ++u) nxt[u] = ldgb(an[u]);       \
   _Pragma("unroll") for (int u = 0; u < FCH; ++u) {                           \
     const double ld = buf[u];                                                 \
     if (__builtin_expect(!(msk & (1 << u)), 1)) {                             \
@@ -195,12 +200,10 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   }
     VM_LOAD1(bufA, 0)
     for (int c = 0; c < p.nchunks_fwd; c += 2) {
-      VM_LOAD1(bufB, c + 1)
-      { VM_EXEC_F(bufA, c) }
-      VM_LOAD1(bufA, c + 2)
-      { VM_EXEC_F(bufB, c + 1) }
+      { VM_STEP(bufA, bufB, c) }
+      { VM_STEP(bufB, bufA, c + 1) }
     }
-#undef VM_EXEC_F
+#undef VM_STEP
   }
   const int bad = rc[S_BAD * 64] != 0.0;
 
