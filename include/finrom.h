@@ -107,8 +107,8 @@ typedef struct {
   int32_t n_obs;           /* rows of the observation operator */
   int32_t nasm;            /* entries of asm_idx / asm_w */
   int32_t n_alist;         /* entries of L that carry a value of A and are assembled by the pre-pass (0: fused stream) */
-  int32_t cache_slots;     /* LDS row-cache slots the forward stream assumes (1..126): (cache_slots+2)*512 B of LDS
-                              per wave decide how many interpreter waves share a CU (42 -> 7, 72 -> 4) */
+  int32_t cache_slots;     /* LDS row-cache slots the forward stream assumes (1..126): (cache_slots + 5 [+ xdim for a fused
+                              stream]) * 512 B of LDS per wave decide how many interpreter waves share a CU (45 slots -> 7) */
   int32_t fwd_chunk;       /* ops per prefetch chunk of the forward stream: 8 or 16 */
   int32_t nops_fwd;        /* multiple of 2*fwd_chunk, the last 2*fwd_chunk ops are padding */
   int32_t nops_bwd;        /* multiple of 16 (two 8-op chunks), the last 16 ops are NOPs */
