@@ -615,15 +615,15 @@ int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n, const double* k, 
 }
 
 // FINROM_TRACE=<prefix>: every finrom_solve_pairs call records, per workgroup of the FOM interpreter and of the
-// projection kernel, {start, end, HW_ID, XCC_ID} and rewrites <prefix>.fom.bin / <prefix>.proj.bin (int64 x 4 per
+// projection kernel, {start, end, HW_ID, XCC_ID} and rewrites <prefix>.fom.bin / <prefix>.proj.bin (int64 x 6 per
 // workgroup) after a device synchronisation.  Diagnostic for the co-residency of the two halves.
 static long long* g_trace_buf[2] = {nullptr, nullptr};
 static constexpr size_t kTraceWg = 1u << 18;
 static const char* trace_prefix() { static const char* p = getenv("FINROM_TRACE"); return p; }
 static int trace_dump(const char* kind, long long* dbuf, size_t nwg) {
-  std::vector<long long> h(nwg * 4);
+  std::vector<long long> h(nwg * 6);
   FR_HIP(hipDeviceSynchronize());
-  FR_HIP(hipMemcpy(h.data(), dbuf, nwg * 4 * sizeof(long long), hipMemcpyDeviceToHost));
+  FR_HIP(hipMemcpy(h.data(), dbuf, nwg * 6 * sizeof(long long), hipMemcpyDeviceToHost));
   const std::string path = std::string(trace_prefix()) + "." + kind + ".bin";
   if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }
   return 0;
@@ -654,9 +654,9 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   const bool tracing = trace_prefix() != nullptr;
   if (tracing) {
     for (int i = 0; i < 2; ++i)
-      if (!g_trace_buf[i]) FR_HIP(hipMalloc((void**)&g_trace_buf[i], kTraceWg * 4 * sizeof(long long)));
-    FR_HIP(hipMemset(g_trace_buf[0], 0, kTraceWg * 4 * sizeof(long long)));
-    FR_HIP(hipMemset(g_trace_buf[1], 0, kTraceWg * 4 * sizeof(long long)));
+      if (!g_trace_buf[i]) FR_HIP(hipMalloc((void**)&g_trace_buf[i], kTraceWg * 6 * sizeof(long long)));
+    FR_HIP(hipMemset(g_trace_buf[0], 0, kTraceWg * 6 * sizeof(long long)));
+    FR_HIP(hipMemset(g_trace_buf[1], 0, kTraceWg * 6 * sizeof(long long)));
     FR_HIP(hipDeviceSynchronize());
     fom->d.trace = (size_t)((S + 63) / 64) <= kTraceWg ? g_trace_buf[0] : nullptr;
     rom->d.trace = (size_t)S <= kTraceWg ? g_trace_buf[1] : nullptr;

@@ -59,20 +59,21 @@ struct Scratch {
 // FINROM_TRACE diagnostic: workgroup residency trace (start/end on the 100 MHz real-time counter + where it ran)
 __device__ __forceinline__ void trace_begin(long long* tr, int64_t wg) {
   if (tr != nullptr && threadIdx.x == 0) {
-    tr[wg * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-    tr[wg * 4 + 2] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_REG_HW_ID
-    tr[wg * 4 + 3] = __builtin_amdgcn_s_getreg(20 | (31 << 11));     // HW_REG_XCC_ID
+    tr[wg * 6 + 0] = __builtin_amdgcn_s_memrealtime();
+    tr[wg * 6 + 2] = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_REG_HW_ID
+    tr[wg * 6 + 3] = __builtin_amdgcn_s_getreg(20 | (31 << 11));     // HW_REG_XCC_ID
+    tr[wg * 6 + 4] = __builtin_amdgcn_s_memtime();                   // shader clock ticks
   }
 }
 __device__ __forceinline__ void trace_end(long long* tr, int64_t wg) {
-  if (tr != nullptr && threadIdx.x == 0) tr[wg * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  if (tr != nullptr && threadIdx.x == 0) { tr[wg * 6 + 1] = __builtin_amdgcn_s_memrealtime(); tr[wg * 6 + 5] = __builtin_amdgcn_s_memtime(); }
 }
 
 // ---- FOM ------------------------------------------------------------------------------
 constexpr int FOM_MAX_FUSED_X = 16;   // longest parameter vector the interpreter keeps in LDS (fused assembly)
 constexpr int VM_CHUNK = 8;        // ops whose global operands are fetched together, one chunk ahead
 struct FomDev {
-  long long* trace;   // FINROM_TRACE: per-workgroup {start, end (10 ns ticks), HW_ID, XCC_ID}; nullptr = off
+  long long* trace;   // FINROM_TRACE: per-workgroup {start, end (10 ns ticks), HW_ID, XCC_ID, start, end (shader clock)}; nullptr = off
   int debug_phases;   // bit 0 factor+forward, 1 backward, 2 QoI (FINROM_FOM_PHASES, timing experiments only; default 7)
   int n, nnzL, xdim, n_obs, n_alist, cache_slots, fwd_chunk;
   int gsize;                         // values per sample: nnzL + 2n  (L | 1/L_ii | y,w)

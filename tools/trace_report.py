@@ -7,11 +7,12 @@ prefix = sys.argv[1]
 tr = {}
 for kind in ("fom", "proj"):
     try:
-        a = np.fromfile(f"{prefix}.{kind}.bin", dtype=np.int64).reshape(-1, 4)
+        a = np.fromfile(f"{prefix}.{kind}.bin", dtype=np.int64).reshape(-1, 6)
     except FileNotFoundError:
         continue
-    a = a[a[:, 0] != 0]
-    tr[kind] = a
+    a = a[(a[:, 0] != 0) & (a[:, 1] != 0)]
+    if len(a):
+        tr[kind] = a
 t0 = min(a[:, 0].min() for a in tr.values())
 for kind, a in tr.items():
     st, en = (a[:, 0] - t0) * 1e-5, (a[:, 1] - t0) * 1e-5          # ms
@@ -25,5 +26,8 @@ for kind, a in tr.items():
     print("   resident workgroups at", " ".join(f"{t:.0f}ms:{r}" for t, r in zip(edges, res)))
     percu = np.bincount(np.unique(cu, return_inverse=True)[1][(st <= edges[3]) & (en > edges[3])])
     print("   per-CU resident at t=%.1f ms: min %d max %d mean %.2f" % (edges[3], percu.min(), percu.max(), percu.mean()))
+    mhz = (a[:, 5] - a[:, 4]) / np.maximum(a[:, 1] - a[:, 0], 1) * 100.0       # shader ticks per 10 ns tick
+    print("   shader clock over the workgroups: min %.0f median %.0f max %.0f MHz; median cycles per workgroup %.0f"
+          % (mhz.min(), np.median(mhz), mhz.max(), np.median(a[:, 5] - a[:, 4])))
     sim = (hw >> 4) & 3
     print("   SIMD histogram of wave 0:", np.bincount(sim, minlength=4))
