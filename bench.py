@@ -61,11 +61,65 @@ def flops_per_pair(ops, plan, rom, n_obs, P):
     }
 
 
+# ---- all-core CPU baseline: worker processes, started BEFORE anything touches the GPU ----------------
+_W = {}
+
+
+def _w_init(m, params, phi):
+    os.environ["OMP_NUM_THREADS"] = "1"
+    try:
+        from threadpoolctl import threadpool_limits
+        _W["lim"] = threadpool_limits(limits=1)
+    except Exception:
+        pass
+    from oracle import fin_oracle as O
+    prob = O.FinProblem(m)
+    _W["fo"], _W["ro"] = O.FinOracle(prob), O.AffineROMOracle(prob, phi)
+    _W["lift"] = _W["fo"].five_param_to_function if params == "five" else _W["fo"].nine_param_to_function
+
+
+def _w_run(X):
+    fo, ro, lift = _W["fo"], _W["ro"], _W["lift"]
+    acc = 0.0
+    for x in X:
+        k = lift(x)
+        acc += float(fo.qoi_operator(fo.forward(k))[0] + ro.qoi_reduced(ro.forward_reduced(k))[0])
+    return len(X), acc
+
+
+def cpu_baseline_all_cores(args):
+    """The same one-sample-at-a-time oracle loop in os.cpu_count() worker processes over sample shards (one thread each)."""
+    import multiprocessing as mp
+    from oracle import fin_oracle as O
+    n = max(1, min(os.cpu_count() or 1, 16))          # the one-GPU box grants 16 CPUs
+    prob = O.FinProblem(args.m)
+    fo = O.FinOracle(prob)
+    rng = np.random.default_rng(1)
+    lift, dim = (fo.five_param_to_function, 5) if args.params == "five" else (fo.nine_param_to_function, 9)
+    Y = np.array([fo.forward(lift(rng.uniform(0.1, 3.5, dim))) for _ in range(max(2 * args.r, 100))])
+    phi = O.pod_basis(Y, args.r)
+    per = max(50, args.cpu_samples // 2)
+    X = np.random.default_rng(3).uniform(0.1, 10.0, (n * per, dim))
+    with mp.get_context("spawn").Pool(n, initializer=_w_init, initargs=(args.m, args.params, phi)) as pool:
+        pool.map(_w_run, [X[i:i + 2] for i in range(0, 2 * n, 2)])                  # every worker built its operators
+        t0 = time.perf_counter()
+        done = sum(c for c, _ in pool.map(_w_run, [X[i * per:(i + 1) * per] for i in range(n)], chunksize=1))
+        dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "pairs/s", "cores": n, "kind": "port",
+            "sample": f"{done} samples of the same distribution in {n} worker processes x 1 thread, oracle/fin_oracle.py loop"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_all = None
+    if world == 1 and args.cpu_samples > 0 and args.params != "field":
+        try:
+            cpu_all = cpu_baseline_all_cores(args)        # worker processes must be gone before the GPU is initialised
+        except Exception as e:                             # context only: never fail the bench for it
+            cpu_all = {"error": repr(e)}
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -210,6 +264,7 @@ def main():
             "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0},
             "kernels_serial_ms": serial_ms,
             "host_io_pairs_per_s": host_io,
+            "cpu_baseline_all_cores": cpu_all,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
