@@ -361,3 +361,15 @@ def test_grad_romml_parity(problems, spaces, tmp_path):
     for s in range(5):
         go, lo = O.grad_romml_oracle(ro, model, K[s])
         assert abs(res["loss"][s] - lo) < 1e-5 * lo and np.linalg.norm(res["grad"][s] - go) < 1e-4 * np.linalg.norm(go)
+
+
+def test_unsupported_basis_size_is_an_error_not_a_crash(spaces):
+    """r > 208 (13 blocks of 16) is outside the projection kernels' range: the ROM handle is created, the solve reports
+    FINROM_ERR_UNSUPPORTED through the Python layer."""
+    from bayesianinferencedl_amd._ffi import FinromError
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    V = spaces(4)
+    rng = np.random.default_rng(0)
+    phi = np.linalg.qr(rng.standard_normal((V.dim(), 209)))[0]
+    with pytest.raises(FinromError):
+        AffineROMFin(V, None, phi).forward_nine_param_reduced_batch(np.ones((2, 9)))
