@@ -37,6 +37,15 @@ class FomGradDesc(C.Structure):
                 ("g_ptr", c_i32p), ("g_a", c_i32p), ("g_b", c_i32p), ("g_w", c_f64p)]
 
 
+class FomSmallDesc(C.Structure):
+    _fields_ = [("small_max", C.c_int32), ("npairs", C.c_int32), ("nasm", C.c_int32), ("nlev_f", C.c_int32), ("nlev_b", C.c_int32),
+                ("row_ptr", c_i32p), ("ent_col", c_i32p),
+                ("pair_ptr", c_i32p), ("pair_a", c_i32p), ("pair_b", c_i32p),
+                ("asm_c0", c_f64p), ("asm_ptr", c_i32p), ("asm_idx", c_i32p), ("asm_w", c_f64p),
+                ("col_ptr", c_i32p), ("col_ent", c_i32p), ("col_row", c_i32p),
+                ("lev_ptr_f", c_i32p), ("lev_rows_f", c_i32p), ("lev_ptr_b", c_i32p), ("lev_rows_b", c_i32p)]
+
+
 class RomDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("r", C.c_int32), ("P", C.c_int32), ("n_obs", C.c_int32),
                 ("nterms", C.c_int32),
@@ -64,6 +73,7 @@ SIGNATURES = {
     "finrom_fom_create": (C.c_int, [C.POINTER(FomDesc), C.POINTER(C.c_void_p)]),
     "finrom_fom_destroy": (None, [C.c_void_p]),
     "finrom_fom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finrom_fom_set_small": (C.c_int, [C.c_void_p, C.POINTER(FomSmallDesc)]),
     "finrom_fom_set_gradient": (C.c_int, [C.c_void_p, C.POINTER(FomGradDesc)]),
     "finrom_fom_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 5),
     "finrom_rom_create": (C.c_int, [C.POINTER(RomDesc), C.POINTER(C.c_void_p)]),
@@ -102,7 +112,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 3:
+        if L.finrom_version() != 4:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

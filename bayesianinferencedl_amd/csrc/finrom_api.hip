@@ -76,6 +76,7 @@ using namespace finrom;
 
 struct finrom_fom_s {
   FomDev d{};
+  FomSmallDev small{};
   std::vector<void*> owned;
   Scratch xT, Gw, gradT, qtmp;
 };
@@ -296,6 +297,12 @@ static int64_t fom_chunk_samples(const FomDev& d) {
 static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, hipStream_t st,
                             int stages) {
   const FomDev& d = h->d;
+  if (h->small.small_max > 0 && S <= h->small.small_max) {      // small batch: latency-oriented schedule, one workgroup per sample
+    if (!(stages & 2)) return 0;
+    int rc;
+    if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;
+    return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, qoi, w, info, st);
+  }
   const int64_t chunk = fom_chunk_samples(d);
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t Sc = std::min(chunk, S - s0);
@@ -318,6 +325,92 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
 int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, void* stream) {
   if (!h || S < 0 || (S > 0 && (!x || (!qoi && h->d.n_obs > 0)))) { set_error("fom_solve: bad argument"); return FINROM_ERR_ARG; }
   return fom_solve_stages(h, x, S, qoi, w, info, (hipStream_t)stream, 3);
+}
+
+int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* a) {
+  if (!h || !a || a->small_max < 0 || a->npairs < 0 || a->nasm < 0 || a->nlev_f <= 0 || a->nlev_b <= 0) { set_error("fom_set_small: bad argument"); return FINROM_ERR_ARG; }
+  const FomDev& d = h->d;
+  const int n = d.n, nnzL = d.nnzL;
+  auto bad = [&](const char* what) { set_error(std::string("fom_set_small: invalid ") + what); return FINROM_ERR_ARG; };
+  // every index the kernel dereferences, and the level property (a row only reads rows of lower levels)
+  if (a->row_ptr[0] != 0 || a->row_ptr[n] != nnzL) return bad("row_ptr");
+  std::vector<int> ent_row(nnzL);
+  for (int i = 0; i < n; ++i) {
+    if (a->row_ptr[i + 1] <= a->row_ptr[i]) return bad("row_ptr");
+    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e) {
+      ent_row[e] = i;
+      const int j = a->ent_col[e];
+      if (j < 0 || j > i || (e == a->row_ptr[i + 1] - 1) != (j == i)) return bad("ent_col (diagonal must close its row)");
+    }
+  }
+  if (a->pair_ptr[0] != 0 || a->pair_ptr[nnzL] != a->npairs) return bad("pair_ptr");
+  if (a->asm_ptr[0] != 0 || a->asm_ptr[nnzL] != a->nasm) return bad("asm_ptr");
+  for (int e = 0; e < nnzL; ++e) {
+    if (a->pair_ptr[e + 1] < a->pair_ptr[e] || a->asm_ptr[e + 1] < a->asm_ptr[e]) return bad("pair_ptr / asm_ptr");
+    for (int k = a->pair_ptr[e]; k < a->pair_ptr[e + 1]; ++k) {
+      const int pa = a->pair_a[k], pb = a->pair_b[k];
+      if (pa < a->row_ptr[ent_row[e]] || pa >= e || pb < 0 || pb >= nnzL || ent_row[pb] != a->ent_col[e]) return bad("pair");
+    }
+  }
+  for (int t = 0; t < a->nasm; ++t) if (a->asm_idx[t] < 0 || a->asm_idx[t] >= d.xdim) return bad("asm_idx");
+  if (a->col_ptr[0] != 0 || a->col_ptr[n] != nnzL - n) return bad("col_ptr");
+  for (int j = 0; j < n; ++j) {
+    if (a->col_ptr[j + 1] < a->col_ptr[j]) return bad("col_ptr");
+    for (int c = a->col_ptr[j]; c < a->col_ptr[j + 1]; ++c) {
+      const int e = a->col_ent[c];
+      if (e < 0 || e >= nnzL || a->ent_col[e] != j || ent_row[e] != a->col_row[c] || a->col_row[c] <= j) return bad("column view");
+    }
+  }
+  auto levels_ok = [&](const int* ptr, const int* rows, int nlev, bool forward) {
+    if (ptr[0] != 0 || ptr[nlev] != n) return false;
+    std::vector<int> lev(n, -1);
+    for (int l = 0; l < nlev; ++l) {
+      if (ptr[l + 1] < ptr[l]) return false;
+      for (int t = ptr[l]; t < ptr[l + 1]; ++t) { const int i = rows[t]; if (i < 0 || i >= n || lev[i] >= 0) return false; lev[i] = l; }
+    }
+    for (int i = 0; i < n; ++i) {
+      if (lev[i] < 0) return false;
+      if (forward) { for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1] - 1; ++e) if (lev[a->ent_col[e]] >= lev[i]) return false; }
+      else { for (int c = a->col_ptr[i]; c < a->col_ptr[i + 1]; ++c) if (lev[a->col_row[c]] >= lev[i]) return false; }
+    }
+    return true;
+  };
+  if (!levels_ok(a->lev_ptr_f, a->lev_rows_f, a->nlev_f, true)) return bad("forward levels");
+  if (!levels_ok(a->lev_ptr_b, a->lev_rows_b, a->nlev_b, false)) return bad("backward levels");
+  FomSmallDev q;
+  int rc = 0;
+  // device layout for latency: one 32-B record per entry, (a, b) pairs and (entry, row) column items as 8-B items
+  std::vector<FomSmallEntry> ent(nnzL);
+  std::vector<int2> pairs;
+  for (int e = 0; e < nnzL; ++e) {
+    FomSmallEntry& r = ent[e];
+    const int k0 = a->pair_ptr[e], np = a->pair_ptr[e + 1] - k0;
+    r.npair = np; r.over0 = (int)pairs.size(); r.asm0 = a->asm_ptr[e]; r.nasm = a->asm_ptr[e + 1] - a->asm_ptr[e];
+    r.col = a->ent_col[e]; r.pad = 0; r.c0 = a->asm_c0[e];
+    r.aidx0 = r.nasm > 0 ? a->asm_idx[r.asm0] : 0; r.aw0 = r.nasm > 0 ? a->asm_w[r.asm0] : 0.0;
+    r.aidx1 = r.nasm > 1 ? a->asm_idx[r.asm0 + 1] : 0; r.aw1 = r.nasm > 1 ? a->asm_w[r.asm0 + 1] : 0.0;
+    for (int u = 0; u < 16; ++u) r.first[u] = u < np ? int2{a->pair_a[k0 + u], a->pair_b[k0 + u]} : int2{0, 0};
+    for (int u = 16; u < np; ++u) pairs.push_back(int2{a->pair_a[k0 + u], a->pair_b[k0 + u]});
+  }
+  pairs.resize(pairs.size() + 32, int2{0, 0});
+  std::vector<int2> colv((size_t)(nnzL - n) + 8, int2{0, 0});
+  for (int c = 0; c < nnzL - n; ++c) colv[c] = int2{a->col_ent[c], a->col_row[c]};
+  if (!rc) rc = up(h->owned, &q.row_ptr, a->row_ptr, n + 1);
+  if (!rc) rc = up(h->owned, &q.ent, ent.data(), ent.size());
+  if (!rc) rc = up(h->owned, &q.pairs, pairs.data(), pairs.size());
+  if (!rc) rc = up(h->owned, &q.asm_idx, a->asm_idx, a->nasm);
+  if (!rc) rc = up(h->owned, &q.asm_w, a->asm_w, a->nasm);
+  if (!rc) rc = up(h->owned, &q.col_ptr, a->col_ptr, n + 1);
+  if (!rc) rc = up(h->owned, &q.colv, colv.data(), colv.size());
+  if (!rc) rc = up(h->owned, &q.lev_ptr_f, a->lev_ptr_f, a->nlev_f + 1);
+  if (!rc) rc = up(h->owned, &q.lev_rows_f, a->lev_rows_f, n);
+  if (!rc) rc = up(h->owned, &q.lev_ptr_b, a->lev_ptr_b, a->nlev_b + 1);
+  if (!rc) rc = up(h->owned, &q.lev_rows_b, a->lev_rows_b, n);
+  if (rc) return rc;
+  q.small_max = a->small_max; q.nlev_f = a->nlev_f; q.nlev_b = a->nlev_b;
+  q.in_lds = (size_t)(nnzL + 3 * n + d.xdim) * sizeof(double) <= (size_t)156 * 1024;      // value vector (+ adjoint region) + x
+  h->small = q;
+  return 0;
 }
 
 int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* a) {

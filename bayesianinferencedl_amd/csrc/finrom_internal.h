@@ -93,6 +93,21 @@ struct FomDev {
   const int* bt_ptr; const int* bt_obs; const double* bt_w;
   const int* g_ptr; const int* g_a; const int* g_b; const double* g_w;
 };
+// one record per entry of L: header + its first 16 index pairs (lane sl of a 16-lane group reads first[sl]); the
+// address depends on the entry number only, so records several entries ahead can be in flight
+struct FomSmallEntry { int npair, over0, asm0, nasm, col, aidx0, aidx1, pad; double c0, aw0, aw1; int2 first[16]; };   // 184 B
+                                     // (aidx/aw: the first two terms of A_e = c0 + sum_t w_t x[idx_t]; further terms at asm0 + 2 ..)
+struct FomSmallDev {                 // latency-oriented schedule for small batches (finrom_fom_set_small)
+  int small_max = 0, nlev_f = 0, nlev_b = 0, in_lds = 0;
+  const int* row_ptr = nullptr;
+  const FomSmallEntry* ent = nullptr;                   // [nnzL]
+  const int2* pairs = nullptr;                          // index pairs beyond the 16th of their entry (over0 .. ), padded
+  const int* asm_idx = nullptr; const double* asm_w = nullptr;
+  const int* col_ptr = nullptr; const int2* colv = nullptr;   // [nnzL - n] (entry, row)
+  const int* lev_ptr_f = nullptr; const int* lev_rows_f = nullptr; const int* lev_ptr_b = nullptr; const int* lev_rows_b = nullptr;
+};
+int launch_fom_small(const FomDev& p, const FomSmallDev& q, const double* x, int64_t S, double* Gscratch, double* qoi, double* w,
+                     int* info, hipStream_t st);
 int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, const double* qoi, const double* data,
                        int64_t data_stride, double* gradT, double* J, hipStream_t st);
 int launch_unpack(const double* srcT, int64_t S, int d, int64_t blk_stride, int off, const int* perm, double* dst, hipStream_t st);

@@ -14,6 +14,7 @@
 // row being eliminated, the "b" operand from global memory, fetched one 8-op chunk ahead.
 // Bound: HBM/L2 bandwidth (one 8-B load per multiply-add and sample, no reuse in registers).
 #include "finrom_internal.h"
+#include <type_traits>
 
 namespace finrom {
 
@@ -371,6 +372,130 @@ int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, con
   const size_t lds = (size_t)(p.n_obs > 0 ? p.n_obs : 1) * 64 * sizeof(double);
   hipLaunchKernelGGL(fom_adjoint_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, p.r_a, p.r_kb, p.r_d, p.bt_ptr, p.bt_obs,
                      p.bt_w, p.g_ptr, p.g_a, p.g_b, p.g_w, Gw, S, qoi, data, data_stride, gradT, J);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Small batches (the scalar call surface): one workgroup per sample, lane = ROW of L.  Rows are grouped into
+// dependency levels (row i needs the rows of its structure); within a level every thread runs the plain up-looking
+// row recurrence for its row, all operands in the sample's value vector V = [L | 1/L_ii | y -> w], which lives in LDS
+// when it fits.  One barrier per level.  ~0.05 of the latency of a lone interpreter wave.
+// ---------------------------------------------------------------------------------------
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void fom_small_kernel(FomDev p, FomSmallDev q, const double* __restrict__ x, int64_t S,
+                                                        double* __restrict__ Gscratch, double* __restrict__ qoi,
+                                                        double* __restrict__ w, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double vlds[];
+  __shared__ int bad_flag;
+  __shared__ double red[4];
+  const int64_t s = blockIdx.x;
+  const int tid = threadIdx.x;
+  double* V = IN_LDS ? vlds : Gscratch + s * (int64_t)p.gsize;
+  // the parameter vector sits in LDS behind the value vector (a per-entry global round trip otherwise)
+  double* xs = vlds + (IN_LDS ? p.gsize : 0);
+  for (int j = tid; j < p.xdim; j += 256) xs[j] = x[s * (int64_t)p.xdim + j];
+  const int IV = p.nnzL, YV = p.nnzL + p.n;
+  if (tid == 0) bad_flag = 0;
+  __syncthreads();
+  // ---- factorisation fused with L y = F, level by level.  Latency matters here, not bandwidth: levels are narrow
+  // (median 3 rows at the fin), so SIXTEEN lanes share a row -- the index pairs of an entry are spread over them, the
+  // partial sums meet in an xor butterfly inside the 16-lane group -- and the record + first index pairs of the next
+  // entry are fetched while the current entry is being reduced.  The lanes of a group sit in one wave: the LDS write of
+  // an entry is ordered before the reads of the following entries without a barrier.
+  const int sg = tid >> 4, sl = tid & 15;
+  // all-reduce over the 16 lanes of a DPP row by rotations (v_mov_b32 row_ror: register-to-register, no LDS crossbar)
+  auto ror = [](double v, auto n) {
+    constexpr int ctrl = 0x120 + decltype(n)::value;
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, ctrl, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), ctrl, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  };
+  auto group_sum = [&](double v) {
+    v += ror(v, std::integral_constant<int, 8>{}); v += ror(v, std::integral_constant<int, 4>{});
+    v += ror(v, std::integral_constant<int, 2>{}); v += ror(v, std::integral_constant<int, 1>{});
+    return v;
+  };
+  for (int l = 0; l < q.nlev_f; ++l) {
+    for (int t = q.lev_ptr_f[l] + sg; t < q.lev_ptr_f[l + 1]; t += 16) {
+      const int i = q.lev_rows_f[t];
+      const int e0 = q.row_ptr[i], e1 = q.row_ptr[i + 1];
+      double yacc = p.rhs[i];
+      // records (header + this lane's first pair) of the next three entries are always in flight
+      struct Hd { int npair, over0, asm0, nasm, col, aidx0, aidx1; double c0, aw0, aw1; int2 pr; };
+      auto fetch = [&](int e) {
+        const FomSmallEntry* r = q.ent + (e < p.nnzL ? e : p.nnzL - 1);
+        return Hd{r->npair, r->over0, r->asm0, r->nasm, r->col, r->aidx0, r->aidx1, r->c0, r->aw0, r->aw1, r->first[sl]};
+      };
+      Hd h1 = fetch(e0), h2 = fetch(e0 + 1), h3 = fetch(e0 + 2);
+      for (int e = e0; e < e1; ++e) {
+        const Hd h = h1;
+        h1 = h2; h2 = h3; h3 = fetch(e + 3);
+        double part = (sl < h.npair) ? -V[h.pr.x] * V[h.pr.y] : 0.0;
+        for (int k = 16 + sl; k < h.npair; k += 16) {
+          const int2 pc = q.pairs[h.over0 + k - 16];
+          part = fma(-V[pc.x], V[pc.y], part);
+        }
+        double acc = fma(h.aw1, xs[h.aidx1], fma(h.aw0, xs[h.aidx0], h.c0));      // unused terms carry a zero weight
+        for (int a = h.asm0 + 2; a < h.asm0 + h.nasm; ++a) acc = fma(q.asm_w[a], xs[q.asm_idx[a]], acc);
+        acc += group_sum(part);                          // the same value in all 16 lanes
+        if (e == e1 - 1) {
+          if (!(acc > 0.0)) bad_flag = 1;
+          const double d = sqrt(acc), inv = 1.0 / d;
+          if (sl == 0) { V[e] = d; V[IV + i] = inv; V[YV + i] = yacc * inv; }
+        } else {
+          const double lij = acc * V[IV + h.col];
+          if (sl == 0) V[e] = lij;
+          yacc = fma(-lij, V[YV + h.col], yacc);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- L^T w = y, w overwrites y
+  for (int l = 0; l < q.nlev_b; ++l) {
+    for (int t = q.lev_ptr_b[l] + sg; t < q.lev_ptr_b[l + 1]; t += 16) {
+      const int i = q.lev_rows_b[t];
+      const int c0 = q.col_ptr[i], c1 = q.col_ptr[i + 1];
+      double part = 0.0;
+      for (int c = c0 + sl; c < c1; c += 16) {
+        const int2 it = q.colv[c];
+        part = fma(-V[it.x], V[YV + it.y], part);
+      }
+      const double wi = (V[YV + i] + group_sum(part)) * V[IV + i];
+      if (sl == 0) V[YV + i] = wi;
+    }
+    __syncthreads();
+  }
+  const bool bad = bad_flag != 0;
+  const double nanv = __builtin_nan("");
+  // ---- QoI = B_obs w, one block reduction per observation
+  for (int o = 0; o < p.n_obs; ++o) {
+    double part = 0.0;
+    for (int t = p.obs_ptr[o] + tid; t < p.obs_ptr[o + 1]; t += 256) part = fma(p.obs_w[t], V[YV + p.obs_idx[t]], part);
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) qoi[s * p.n_obs + o] = bad ? nanv : red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+  if (w != nullptr)
+    for (int i = tid; i < p.n; i += 256) w[s * (int64_t)p.n + p.perm[i]] = bad ? nanv : V[YV + i];
+  if (info != nullptr && tid == 0 && bad) atomicOr(&info[s], 1);
+}
+
+int launch_fom_small(const FomDev& p, const FomSmallDev& q, const double* x, int64_t S, double* Gscratch, double* qoi, double* w,
+                     int* info, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_FOM, st);
+  if (q.in_lds) {
+    const size_t lds = (size_t)(p.gsize + p.xdim) * sizeof(double);
+    FR_HIP(hipFuncSetAttribute((const void*)fom_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fom_small_kernel<true>, dim3((unsigned)S), dim3(256), lds, st, p, q, x, S, Gscratch, qoi, w, info);
+  } else {
+    hipLaunchKernelGGL(fom_small_kernel<false>, dim3((unsigned)S), dim3(256), (size_t)p.xdim * sizeof(double), st, p, q, x, S, Gscratch, qoi, w, info);
+  }
   FR_HIP(hipGetLastError());
   return 0;
 }

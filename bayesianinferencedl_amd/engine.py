@@ -10,7 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _ffi
-from ._ffi import DeviceBuffer, FomDesc, FomGradDesc, RomDesc, check, f64, i32, lib
+from ._ffi import FomSmallDesc, DeviceBuffer, FomDesc, FomGradDesc, RomDesc, check, f64, i32, lib
 
 
 import os as _os
@@ -21,6 +21,11 @@ FWD_CHUNK = int(_os.environ.get("FINROM_FWD_CHUNK", "8"))
 # Parameter vectors of at most FUSED_X_MAX entries (the five / nine fin conductivities) sit in the interpreter's LDS and
 # the op stream assembles A itself (no pre-pass); their slots come out of the row cache so that 7 waves still share a CU.
 FUSED_X_MAX = int(_os.environ.get("FINROM_FUSED_X_MAX", "16"))
+# Batches of at most SMALL_MAX samples (the scalar call surface) use the latency-oriented schedule: one workgroup per
+# sample, 16 lanes per row of L (finrom_fom_set_small).  0 disables it.  Measured cross-over against the interpreter: ~700
+# samples at m = 12 (value vector in LDS, one workgroup per CU), several thousand at m = 20 (value vector in L2).
+SMALL_MAX = int(_os.environ.get("FINROM_SMALL_MAX", "512"))
+SMALL_MAX_GLOBAL = int(_os.environ.get("FINROM_SMALL_MAX_GLOBAL", "4096"))
 
 
 def _is_torch(x):
@@ -111,6 +116,16 @@ class FomEngine:
         h = C.c_void_p()
         check(lib().finrom_fom_create(C.byref(d), C.byref(h)), "finrom_fom_create")
         self._h = h
+        if SMALL_MAX > 0:
+            lpf, lrf, lpb, lrb = plan.level_sets()
+            in_lds = (plan.nnzL + 3 * plan.n + self.xdim) * 8 <= 156 * 1024          # the library's own criterion
+            sd = FomSmallDesc(small_max=SMALL_MAX if in_lds else SMALL_MAX_GLOBAL, npairs=plan.npairs, nasm=len(aidx), nlev_f=len(lpf) - 1, nlev_b=len(lpb) - 1,
+                              row_ptr=I(plan.row_ptr), ent_col=I(plan.ent_col),
+                              pair_ptr=I(plan.pair_ptr), pair_a=I(plan.pair_a), pair_b=I(plan.pair_b),
+                              asm_c0=D(c0), asm_ptr=I(aptr), asm_idx=I(aidx), asm_w=D(aw),
+                              col_ptr=I(plan.col_ptr), col_ent=I(plan.col_ent), col_row=I(plan.col_row),
+                              lev_ptr_f=I(lpf), lev_rows_f=I(lrf), lev_ptr_b=I(lpb), lev_rows_b=I(lrb))
+            check(lib().finrom_fom_set_small(self._h, C.byref(sd)), "finrom_fom_set_small")
 
     def solve(self, X, want_w=False):
         b = _Batch(X, self.xdim)

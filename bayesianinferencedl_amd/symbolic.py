@@ -231,6 +231,33 @@ class CholeskyPlan:
             cache[key] = build_op_streams(self, cache_slots, nz, fwd_chunk, fused_asm)
         return cache[key]
 
+    def level_sets(self):
+        """Dependency levels of the row recurrence for the small-batch kernel (one workgroup per sample, lane = row):
+        forward -- row i needs every row in its structure; backward (L^T w = y) -- row i needs every row below it in
+        column i.  Returns (lev_ptr_f, lev_rows_f, lev_ptr_b, lev_rows_b); rows of a level sorted by decreasing work."""
+        if getattr(self, "_levels", None) is None:
+            n = self.n
+            rp, ec, pp = self.row_ptr.astype(np.int64), self.ent_col.astype(np.int64), self.pair_ptr.astype(np.int64)
+            cp, cr = self.col_ptr.astype(np.int64), self.col_row.astype(np.int64)
+            lf = np.zeros(n, np.int64)
+            for i in range(n):
+                cols = ec[rp[i]:rp[i + 1] - 1]
+                lf[i] = 0 if len(cols) == 0 else lf[cols].max() + 1
+            lb = np.zeros(n, np.int64)
+            for i in range(n - 1, -1, -1):
+                rows = cr[cp[i]:cp[i + 1]]
+                lb[i] = 0 if len(rows) == 0 else lb[rows].max() + 1
+            cost_f = (pp[rp[1:]] - pp[rp[:-1]]) + 2 * np.diff(rp)
+            cost_b = np.diff(cp) + 1
+
+            def pack(lev, cost):
+                order = np.lexsort((-cost, lev))
+                ptr = np.zeros(lev.max() + 2, np.int64)
+                np.cumsum(np.bincount(lev, minlength=lev.max() + 1), out=ptr[1:])
+                return ptr.astype(np.int32), order.astype(np.int32)
+            self._levels = pack(lf, cost_f) + pack(lb, cost_b)
+        return self._levels
+
     def entry_table(self, c0_csr, W_csr):
         """Re-index a sparse-affine value map ``vals = c0 + W @ x`` (defined on the CSR
         pattern of A) onto the entries of L: returns (c0[nnzL], ptr[nnzL+1], idx, w)."""

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 3
+#define FINROM_ABI_VERSION 4
 
 typedef enum {
   FINROM_OK = 0,
@@ -152,6 +152,29 @@ typedef struct {
 int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* desc);
 int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int32_t data_per_sample, int64_t S,
                         double* grad, double* J, double* qoi, int32_t* info, void* stream);
+
+/* ---- FOM, small batches (the scalar call surface: Fin.forward for ONE conductivity, fom :270-291) --------------- *
+ * The interpreter above is a throughput design (lane = sample): a lone wave takes ~12 ms per solve at n = 1597.  For small
+ * batches finrom_fom_set_small installs a second, latency-oriented schedule of the same factorisation: one workgroup per
+ * sample, lane = ROW of L, rows grouped into dependency levels of the elimination (row i needs the rows of its
+ * structure), one barrier per level, the value vector in LDS when it fits (nnzL + 2n doubles <= 152 KiB).  All arrays over
+ * PERMUTED dofs; entries of L ordered as for the interpreter streams: row-major, diagonal last in its row.
+ *   row_ptr/ent_col         structure of L;  pair_ptr/pair_a/pair_b   L_e = (A_e - sum_q L[pair_a[q]] L[pair_b[q]]) (/ L_jj)
+ *   asm_c0/asm_ptr/asm_idx/asm_w   A_e = c0_e + sum_t w_t x[idx_t] per entry (empty range: fill entry)
+ *   col_ptr/col_ent/col_row strictly-lower entries of column j (backward substitution)
+ *   lev_ptr_f/lev_rows_f, lev_ptr_b/lev_rows_b   rows of each forward / backward level
+ * finrom_fom_solve then uses this schedule whenever S <= small_max. */
+typedef struct {
+  int32_t small_max;        /* largest batch solved with this schedule */
+  int32_t npairs, nasm, nlev_f, nlev_b;
+  const int32_t* row_ptr; const int32_t* ent_col;                           /* [n+1], [nnzL] */
+  const int32_t* pair_ptr; const int32_t* pair_a; const int32_t* pair_b;    /* [nnzL+1], [npairs] x 2 */
+  const double*  asm_c0; const int32_t* asm_ptr; const int32_t* asm_idx; const double* asm_w;   /* [nnzL], [nnzL+1], [nasm] x 2 */
+  const int32_t* col_ptr; const int32_t* col_ent; const int32_t* col_row;   /* [n+1], [nnzL-n] x 2 */
+  const int32_t* lev_ptr_f; const int32_t* lev_rows_f;                      /* [nlev_f+1], [n] */
+  const int32_t* lev_ptr_b; const int32_t* lev_rows_b;                      /* [nlev_b+1], [n] */
+} finrom_fom_small_desc;
+int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* desc);
 
 /* ---- ROM: batched LSPG reduced solve ------------------------------------------------- *
  * Replaces AffineROMFin.forward_nine_param_reduced + .qoi_reduced

@@ -25,9 +25,13 @@ def test_oracle_reproduces_golden(problems):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("schedule", ["small-batch schedule", "interpreter"])
 @pytest.mark.parametrize("kind,key", [("five", "k5"), ("nine", "k9"), ("field", "fields")])
-def test_gpu_reproduces_golden(spaces, kind, key):
+def test_gpu_reproduces_golden(spaces, kind, key, schedule, monkeypatch):
     from bayesianinferencedl_amd.pairs import FinPairSolver
+    import bayesianinferencedl_amd.engine as E
+    if schedule == "interpreter":                  # the golden batches are small: also check the throughput schedule
+        monkeypatch.setattr(E, "SMALL_MAX", 0)
     V = spaces(int(G["m"]))
     res = FinPairSolver(V, G["phi"], params=kind).solve_pairs(G[key], want_w=True)
     assert (res["info"] == 0).all()

@@ -10,6 +10,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
+@pytest.fixture(autouse=True, params=["small-batch schedule", "interpreter"])
+def fom_schedule(request, monkeypatch):
+    """Small batches take the latency-oriented FOM schedule (finrom_fom_set_small); every test here also runs with it
+    disabled, so that the throughput interpreter is checked on the same inputs."""
+    import bayesianinferencedl_amd.engine as E
+    if request.param == "interpreter":
+        monkeypatch.setattr(E, "SMALL_MAX", 0)
+    return request.param
+
+
 def rel(a, b):
     a = np.asarray(a); b = np.asarray(b)
     return np.max(np.linalg.norm(a - b, axis=-1) / np.linalg.norm(b, axis=-1))
