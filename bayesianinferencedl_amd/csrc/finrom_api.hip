@@ -379,27 +379,32 @@ int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* a) {
   if (!levels_ok(a->lev_ptr_b, a->lev_rows_b, a->nlev_b, false)) return bad("backward levels");
   FomSmallDev q;
   int rc = 0;
-  // device layout for latency: one 32-B record per entry, (a, b) pairs and (entry, row) column items as 8-B items
-  std::vector<FomSmallEntry> ent(nnzL);
-  std::vector<int2> pairs;
-  for (int e = 0; e < nnzL; ++e) {
-    FomSmallEntry& r = ent[e];
-    const int k0 = a->pair_ptr[e], np = a->pair_ptr[e + 1] - k0;
-    r.npair = np; r.over0 = (int)pairs.size(); r.asm0 = a->asm_ptr[e]; r.nasm = a->asm_ptr[e + 1] - a->asm_ptr[e];
-    r.col = a->ent_col[e]; r.pad = 0; r.c0 = a->asm_c0[e];
-    r.aidx0 = r.nasm > 0 ? a->asm_idx[r.asm0] : 0; r.aw0 = r.nasm > 0 ? a->asm_w[r.asm0] : 0.0;
-    r.aidx1 = r.nasm > 1 ? a->asm_idx[r.asm0 + 1] : 0; r.aw1 = r.nasm > 1 ? a->asm_w[r.asm0 + 1] : 0.0;
-    for (int u = 0; u < 16; ++u) r.first[u] = u < np ? int2{a->pair_a[k0 + u], a->pair_b[k0 + u]} : int2{0, 0};
-    for (int u = 16; u < np; ++u) pairs.push_back(int2{a->pair_a[k0 + u], a->pair_b[k0 + u]});
+  // device layout for latency: a stream of fixed-size records (see FomSmallRec), (entry, row) column items as 8-B items
+  std::vector<FomSmallRec> rec;
+  std::vector<int> rec_ptr(n + 1, 0);
+  for (int i = 0; i < n; ++i) {
+    for (int e = a->row_ptr[i]; e < a->row_ptr[i + 1]; ++e) {
+      const int k0 = a->pair_ptr[e], np = a->pair_ptr[e + 1] - k0, t0 = a->asm_ptr[e], nt = a->asm_ptr[e + 1] - t0;
+      const int nrec = std::max(1, std::max((np + 15) / 16, (nt + 7) / 8));
+      for (int c = 0; c < nrec; ++c) {
+        FomSmallRec r{};
+        r.e = e; r.col = a->ent_col[e];
+        r.npair = std::max(0, std::min(16, np - 16 * c));
+        for (int u = 0; u < r.npair; ++u) r.first[u] = int2{a->pair_a[k0 + 16 * c + u], a->pair_b[k0 + 16 * c + u]};
+        const int ntc = std::max(0, std::min(8, nt - 8 * c));
+        for (int u = 0; u < ntc; ++u) { r.aidx[u] = a->asm_idx[t0 + 8 * c + u]; r.aw[u] = a->asm_w[t0 + 8 * c + u]; }
+        r.c0 = c == 0 ? a->asm_c0[e] : 0.0;
+        r.flags = (c == nrec - 1 ? 1 : 0) | (r.col == i ? 2 : 0) | ((ntc > 0 || r.c0 != 0.0) ? 4 : 0);
+        rec.push_back(r);
+      }
+    }
+    rec_ptr[i + 1] = (int)rec.size();
   }
-  pairs.resize(pairs.size() + 32, int2{0, 0});
+  rec.resize(rec.size() + 6, FomSmallRec{});
   std::vector<int2> colv((size_t)(nnzL - n) + 8, int2{0, 0});
   for (int c = 0; c < nnzL - n; ++c) colv[c] = int2{a->col_ent[c], a->col_row[c]};
-  if (!rc) rc = up(h->owned, &q.row_ptr, a->row_ptr, n + 1);
-  if (!rc) rc = up(h->owned, &q.ent, ent.data(), ent.size());
-  if (!rc) rc = up(h->owned, &q.pairs, pairs.data(), pairs.size());
-  if (!rc) rc = up(h->owned, &q.asm_idx, a->asm_idx, a->nasm);
-  if (!rc) rc = up(h->owned, &q.asm_w, a->asm_w, a->nasm);
+  if (!rc) rc = up(h->owned, &q.rec_ptr, rec_ptr.data(), rec_ptr.size());
+  if (!rc) rc = up(h->owned, &q.rec, rec.data(), rec.size());
   if (!rc) rc = up(h->owned, &q.col_ptr, a->col_ptr, n + 1);
   if (!rc) rc = up(h->owned, &q.colv, colv.data(), colv.size());
   if (!rc) rc = up(h->owned, &q.lev_ptr_f, a->lev_ptr_f, a->nlev_f + 1);

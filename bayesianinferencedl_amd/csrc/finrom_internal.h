@@ -93,16 +93,25 @@ struct FomDev {
   const int* bt_ptr; const int* bt_obs; const double* bt_w;
   const int* g_ptr; const int* g_a; const int* g_b; const double* g_w;
 };
-// one record per entry of L: header + its first 16 index pairs (lane sl of a 16-lane group reads first[sl]); the
-// address depends on the entry number only, so records several entries ahead can be in flight
-struct FomSmallEntry { int npair, over0, asm0, nasm, col, aidx0, aidx1, pad; double c0, aw0, aw1; int2 first[16]; };   // 184 B
-                                     // (aidx/aw: the first two terms of A_e = c0 + sum_t w_t x[idx_t]; further terms at asm0 + 2 ..)
+// The small-batch kernel reads a stream of 256-B records, one per entry of L (entries with more than 16 index pairs or more
+// than 8 assembly terms continue in further records): header, up to 8 terms of A_e = c0 + sum_t w_t x[idx_t], 16 index
+// pairs (lane l of a 16-lane group reads pair l).  The address of a record depends on its number only and the loop over
+// the records of a row contains no other global load, so records several steps ahead can be in flight.
+struct FomSmallRec {
+  int e;            // entry of L this record belongs to
+  int npair;        // index pairs in THIS record (<= 16)
+  int col;          // column of the entry (== row for the diagonal)
+  int flags;        // bit 0: last record of its entry, bit 1: diagonal entry, bit 2: has assembly terms
+  double c0;
+  int aidx[8]; double aw[8];
+  int2 first[16];
+  int pad[2];
+};
+static_assert(sizeof(FomSmallRec) == 256, "record layout");
 struct FomSmallDev {                 // latency-oriented schedule for small batches (finrom_fom_set_small)
   int small_max = 0, nlev_f = 0, nlev_b = 0, in_lds = 0;
-  const int* row_ptr = nullptr;
-  const FomSmallEntry* ent = nullptr;                   // [nnzL]
-  const int2* pairs = nullptr;                          // index pairs beyond the 16th of their entry (over0 .. ), padded
-  const int* asm_idx = nullptr; const double* asm_w = nullptr;
+  const int* rec_ptr = nullptr;                         // [n+1] records of row i
+  const FomSmallRec* rec = nullptr;                     // [nrec + 4] (padded for the lookahead)
   const int* col_ptr = nullptr; const int2* colv = nullptr;   // [nnzL - n] (entry, row)
   const int* lev_ptr_f = nullptr; const int* lev_rows_f = nullptr; const int* lev_ptr_b = nullptr; const int* lev_rows_b = nullptr;
 };

@@ -420,35 +420,48 @@ __global__ __launch_bounds__(256) void fom_small_kernel(FomDev p, FomSmallDev q,
   for (int l = 0; l < q.nlev_f; ++l) {
     for (int t = q.lev_ptr_f[l] + sg; t < q.lev_ptr_f[l + 1]; t += 16) {
       const int i = q.lev_rows_f[t];
-      const int e0 = q.row_ptr[i], e1 = q.row_ptr[i + 1];
-      double yacc = p.rhs[i];
-      // records (header + this lane's first pair) of the next three entries are always in flight
-      struct Hd { int npair, over0, asm0, nasm, col, aidx0, aidx1; double c0, aw0, aw1; int2 pr; };
-      auto fetch = [&](int e) {
-        const FomSmallEntry* r = q.ent + (e < p.nnzL ? e : p.nnzL - 1);
-        return Hd{r->npair, r->over0, r->asm0, r->nasm, r->col, r->aidx0, r->aidx1, r->c0, r->aw0, r->aw1, r->first[sl]};
+      const int r0 = q.rec_ptr[i], r1 = q.rec_ptr[i + 1];
+      double yacc = p.rhs[i], acc = 0.0;
+      // the records of the next three steps are always in flight (the stream is padded by 4 records)
+      struct Hd { int e, npair, col, flags; double c0; int4 ai0, ai1; double aw[8]; int2 pr; };
+      auto fetch = [&](int r) {
+        const FomSmallRec* R = q.rec + r;
+        const int4* ai = reinterpret_cast<const int4*>(R->aidx);
+        Hd h{R->e, R->npair, R->col, R->flags, R->c0, ai[0], ai[1], {}, R->first[sl]};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h.aw[u] = R->aw[u];
+        return h;
       };
-      Hd h1 = fetch(e0), h2 = fetch(e0 + 1), h3 = fetch(e0 + 2);
-      for (int e = e0; e < e1; ++e) {
-        const Hd h = h1;
-        h1 = h2; h2 = h3; h3 = fetch(e + 3);
-        double part = (sl < h.npair) ? -V[h.pr.x] * V[h.pr.y] : 0.0;
-        for (int k = 16 + sl; k < h.npair; k += 16) {
-          const int2 pc = q.pairs[h.over0 + k - 16];
-          part = fma(-V[pc.x], V[pc.y], part);
+      auto process = [&](const Hd& h) {
+        const double part = (sl < h.npair) ? -V[h.pr.x] * V[h.pr.y] : 0.0;
+        if (h.flags & 4) {                               // A_e = c0 + sum_t w_t x[idx_t]; unused terms carry a zero weight
+          double a0 = fma(h.aw[0], xs[h.ai0.x], h.c0), a1 = h.aw[1] * xs[h.ai0.y];
+          a0 = fma(h.aw[2], xs[h.ai0.z], a0); a1 = fma(h.aw[3], xs[h.ai0.w], a1);
+          a0 = fma(h.aw[4], xs[h.ai1.x], a0); a1 = fma(h.aw[5], xs[h.ai1.y], a1);
+          a0 = fma(h.aw[6], xs[h.ai1.z], a0); a1 = fma(h.aw[7], xs[h.ai1.w], a1);
+          acc += a0 + a1;
         }
-        double acc = fma(h.aw1, xs[h.aidx1], fma(h.aw0, xs[h.aidx0], h.c0));      // unused terms carry a zero weight
-        for (int a = h.asm0 + 2; a < h.asm0 + h.nasm; ++a) acc = fma(q.asm_w[a], xs[q.asm_idx[a]], acc);
         acc += group_sum(part);                          // the same value in all 16 lanes
-        if (e == e1 - 1) {
-          if (!(acc > 0.0)) bad_flag = 1;
-          const double d = sqrt(acc), inv = 1.0 / d;
-          if (sl == 0) { V[e] = d; V[IV + i] = inv; V[YV + i] = yacc * inv; }
-        } else {
-          const double lij = acc * V[IV + h.col];
-          if (sl == 0) V[e] = lij;
-          yacc = fma(-lij, V[YV + h.col], yacc);
+        if (h.flags & 1) {                               // last record of the entry: finish it
+          if (h.flags & 2) {
+            if (!(acc > 0.0)) bad_flag = 1;
+            const double d = sqrt(acc), inv = 1.0 / d;
+            if (sl == 0) { V[h.e] = d; V[IV + i] = inv; V[YV + i] = yacc * inv; }
+          } else {
+            const double lij = acc * V[IV + h.col];
+            if (sl == 0) V[h.e] = lij;
+            yacc = fma(-lij, V[YV + h.col], yacc);
+          }
+          acc = 0.0;
         }
+      };
+      // three record buffers with fixed roles (rotating them through register copies would make every step wait for the
+      // youngest load): consume one, refill it with the record three steps ahead
+      Hd ha = fetch(r0), hb = fetch(r0 + 1), hc = fetch(r0 + 2);
+      for (int r = r0; r < r1; r += 3) {
+        { const Hd h = ha; ha = fetch(r + 3); process(h); }
+        if (r + 1 < r1) { const Hd h = hb; hb = fetch(r + 4); process(h); }
+        if (r + 2 < r1) { const Hd h = hc; hc = fetch(r + 5); process(h); }
       }
     }
     __syncthreads();
