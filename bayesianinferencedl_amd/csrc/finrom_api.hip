@@ -403,6 +403,8 @@ int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* a) {
   rec.resize(rec.size() + 6, FomSmallRec{});
   std::vector<int2> colv((size_t)(nnzL - n) + 8, int2{0, 0});
   for (int c = 0; c < nnzL - n; ++c) colv[c] = int2{a->col_ent[c], a->col_row[c]};
+  if (!rc) rc = up(h->owned, &q.row_ptr, a->row_ptr, n + 1);
+  if (!rc) rc = up(h->owned, &q.ent_col, a->ent_col, nnzL);
   if (!rc) rc = up(h->owned, &q.rec_ptr, rec_ptr.data(), rec_ptr.size());
   if (!rc) rc = up(h->owned, &q.rec, rec.data(), rec.size());
   if (!rc) rc = up(h->owned, &q.col_ptr, a->col_ptr, n + 1);
@@ -470,6 +472,15 @@ int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int
   if (!h->d.has_grad) { set_error("fom_gradient: finrom_fom_set_gradient has not been called"); return FINROM_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const FomDev& d = h->d;
+  if (h->small.small_max > 0 && S <= h->small.small_max && d.n_obs <= 64) {      // small batch: value and gradient in one workgroup per sample
+    int rc;
+    if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;
+    double* q = qoi;
+    if (!q) { if ((rc = h->qtmp.reserve((size_t)S * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
+    FomSmallGrad g;
+    g.data = data; g.data_stride = data_per_sample ? d.n_obs : 0; g.grad = grad; g.J = J;
+    return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, q, nullptr, info, st, g);
+  }
   const size_t per_sample = ((size_t)d.gsize + 2 * d.xdim) * sizeof(double);
   int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
   chunk = std::max<int64_t>(64, chunk / 64 * 64);

@@ -110,13 +110,18 @@ struct FomSmallRec {
 static_assert(sizeof(FomSmallRec) == 256, "record layout");
 struct FomSmallDev {                 // latency-oriented schedule for small batches (finrom_fom_set_small)
   int small_max = 0, nlev_f = 0, nlev_b = 0, in_lds = 0;
+  const int* row_ptr = nullptr; const int* ent_col = nullptr;   // structure of L (adjoint substitution)
   const int* rec_ptr = nullptr;                         // [n+1] records of row i
   const FomSmallRec* rec = nullptr;                     // [nrec + 4] (padded for the lookahead)
   const int* col_ptr = nullptr; const int2* colv = nullptr;   // [nnzL - n] (entry, row)
   const int* lev_ptr_f = nullptr; const int* lev_rows_f = nullptr; const int* lev_ptr_b = nullptr; const int* lev_rows_b = nullptr;
 };
+struct FomSmallGrad {                // adjoint-gradient stage of the small-batch kernel (finrom_fom_gradient, S <= small_max)
+  const double* data = nullptr; int64_t data_stride = 0;   // observations [n_obs] (stride 0) or [S x n_obs]
+  double* grad = nullptr; double* J = nullptr;              // [S x xdim], [S]
+};
 int launch_fom_small(const FomDev& p, const FomSmallDev& q, const double* x, int64_t S, double* Gscratch, double* qoi, double* w,
-                     int* info, hipStream_t st);
+                     int* info, hipStream_t st, const FomSmallGrad& g = FomSmallGrad());
 int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, const double* qoi, const double* data,
                        int64_t data_stride, double* gradT, double* J, hipStream_t st);
 int launch_unpack(const double* srcT, int64_t S, int d, int64_t blk_stride, int off, const int* perm, double* dst, hipStream_t st);

@@ -385,10 +385,11 @@ int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, con
 template <bool IN_LDS>
 __global__ __launch_bounds__(256) void fom_small_kernel(FomDev p, FomSmallDev q, const double* __restrict__ x, int64_t S,
                                                         double* __restrict__ Gscratch, double* __restrict__ qoi,
-                                                        double* __restrict__ w, int* __restrict__ info) {
+                                                        double* __restrict__ w, int* __restrict__ info, FomSmallGrad ga) {
   extern __shared__ __attribute__((aligned(16))) double vlds[];
   __shared__ int bad_flag;
   __shared__ double red[4];
+  __shared__ double resid[64];
   const int64_t s = blockIdx.x;
   const int tid = threadIdx.x;
   double* V = IN_LDS ? vlds : Gscratch + s * (int64_t)p.gsize;
@@ -490,8 +491,61 @@ __global__ __launch_bounds__(256) void fom_small_kernel(FomDev p, FomSmallDev q,
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
-    if (tid == 0) qoi[s * p.n_obs + o] = bad ? nanv : red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) {
+      const double qv = red[0] + red[1] + red[2] + red[3];
+      qoi[s * p.n_obs + o] = bad ? nanv : qv;
+      if (ga.grad != nullptr) resid[o] = qv - ga.data[(ga.data_stride ? s * ga.data_stride : 0) + o];
+    }
     __syncthreads();
+  }
+  // ---- adjoint gradient (Fin.gradient, fom :293-322) with the factor still in place:  b = -B_obs^T r,  L L^T v = b,
+  //      grad_j = sum dA_ab/dx_j v_a w_b,  J = |r|^2 / 2
+  if (ga.grad != nullptr) {
+    const int VV = p.nnzL + 2 * p.n;
+    for (int i = tid; i < p.n; i += 256) {
+      double acc = 0.0;
+      for (int t = p.bt_ptr[i]; t < p.bt_ptr[i + 1]; ++t) acc = fma(-p.bt_w[t], resid[p.bt_obs[t]], acc);
+      V[VV + i] = acc;
+    }
+    __syncthreads();
+    for (int l = 0; l < q.nlev_f; ++l) {                 // L z = b, rows level by level, 16 lanes per row
+      for (int t = q.lev_ptr_f[l] + sg; t < q.lev_ptr_f[l + 1]; t += 16) {
+        const int i = q.lev_rows_f[t];
+        const int e0 = q.row_ptr[i], e1 = q.row_ptr[i + 1] - 1;
+        double part = 0.0;
+        for (int e = e0 + sl; e < e1; e += 16) part = fma(-V[e], V[VV + q.ent_col[e]], part);
+        const double zi = (V[VV + i] + group_sum(part)) * V[IV + i];
+        if (sl == 0) V[VV + i] = zi;
+      }
+      __syncthreads();
+    }
+    for (int l = 0; l < q.nlev_b; ++l) {                 // L^T v = z
+      for (int t = q.lev_ptr_b[l] + sg; t < q.lev_ptr_b[l + 1]; t += 16) {
+        const int i = q.lev_rows_b[t];
+        const int c0 = q.col_ptr[i], c1 = q.col_ptr[i + 1];
+        double part = 0.0;
+        for (int c = c0 + sl; c < c1; c += 16) {
+          const int2 it = q.colv[c];
+          part = fma(-V[it.x], V[VV + it.y], part);
+        }
+        const double vi = (V[VV + i] + group_sum(part)) * V[IV + i];
+        if (sl == 0) V[VV + i] = vi;
+      }
+      __syncthreads();
+    }
+    for (int j0 = 0; j0 < p.xdim; j0 += 16) {            // one 16-lane group per parameter
+      const int j = j0 + sg;
+      double part = 0.0;
+      if (j < p.xdim)
+        for (int t = p.g_ptr[j] + sl; t < p.g_ptr[j + 1]; t += 16) part = fma(p.g_w[t], V[VV + p.g_a[t]] * V[YV + p.g_b[t]], part);
+      part = group_sum(part);
+      if (j < p.xdim && sl == 0) ga.grad[s * (int64_t)p.xdim + j] = bad ? nanv : part;
+    }
+    if (tid == 0) {
+      double jl = 0.0;
+      for (int o = 0; o < p.n_obs; ++o) jl = fma(resid[o], resid[o], jl);
+      ga.J[s] = bad ? nanv : 0.5 * jl;
+    }
   }
   if (w != nullptr)
     for (int i = tid; i < p.n; i += 256) w[s * (int64_t)p.n + p.perm[i]] = bad ? nanv : V[YV + i];
@@ -499,15 +553,15 @@ __global__ __launch_bounds__(256) void fom_small_kernel(FomDev p, FomSmallDev q,
 }
 
 int launch_fom_small(const FomDev& p, const FomSmallDev& q, const double* x, int64_t S, double* Gscratch, double* qoi, double* w,
-                     int* info, hipStream_t st) {
+                     int* info, hipStream_t st, const FomSmallGrad& g) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_FOM, st);
   if (q.in_lds) {
     const size_t lds = (size_t)(p.gsize + p.xdim) * sizeof(double);
     FR_HIP(hipFuncSetAttribute((const void*)fom_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(fom_small_kernel<true>, dim3((unsigned)S), dim3(256), lds, st, p, q, x, S, Gscratch, qoi, w, info);
+    hipLaunchKernelGGL(fom_small_kernel<true>, dim3((unsigned)S), dim3(256), lds, st, p, q, x, S, Gscratch, qoi, w, info, g);
   } else {
-    hipLaunchKernelGGL(fom_small_kernel<false>, dim3((unsigned)S), dim3(256), (size_t)p.xdim * sizeof(double), st, p, q, x, S, Gscratch, qoi, w, info);
+    hipLaunchKernelGGL(fom_small_kernel<false>, dim3((unsigned)S), dim3(256), (size_t)p.xdim * sizeof(double), st, p, q, x, S, Gscratch, qoi, w, info, g);
   }
   FR_HIP(hipGetLastError());
   return 0;

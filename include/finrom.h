@@ -163,7 +163,7 @@ int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int
  *   asm_c0/asm_ptr/asm_idx/asm_w   A_e = c0_e + sum_t w_t x[idx_t] per entry (empty range: fill entry)
  *   col_ptr/col_ent/col_row strictly-lower entries of column j (backward substitution)
  *   lev_ptr_f/lev_rows_f, lev_ptr_b/lev_rows_b   rows of each forward / backward level
- * finrom_fom_solve then uses this schedule whenever S <= small_max. */
+ * finrom_fom_solve and finrom_fom_gradient then use this schedule whenever S <= small_max. */
 typedef struct {
   int32_t small_max;        /* largest batch solved with this schedule */
   int32_t npairs, nasm, nlev_f, nlev_b;
