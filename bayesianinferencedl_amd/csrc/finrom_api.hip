@@ -303,7 +303,9 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
     if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;
     return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, qoi, w, info, st);
   }
-  const int64_t chunk = fom_chunk_samples(d);
+  // equal pieces when the batch exceeds the workspace bound (a short last piece would leave the GPU mostly idle)
+  const int64_t limit = fom_chunk_samples(d), npieces = (S + limit - 1) / limit;
+  const int64_t chunk = npieces <= 1 ? limit : ((S + npieces - 1) / npieces + 63) / 64 * 64;
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t Sc = std::min(chunk, S - s0);
     const int64_t nblk = (Sc + 63) / 64;
@@ -648,6 +650,7 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
   const RomDev& d = h->d;
   const size_t per_sample = ((size_t)d.rp * (d.rp + 1) / 2 + d.rp) * sizeof(double);
   int64_t chunk = std::max<int64_t>(4, (int64_t)(((size_t)16 << 30) / per_sample) / 4 * 4);
+  if (S > chunk) { const int64_t np = (S + chunk - 1) / chunk; chunk = ((S + np - 1) / np + 3) / 4 * 4; }      // equal pieces
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t Sc = std::min(chunk, S - s0);
     int rc;
