@@ -383,3 +383,38 @@ def test_unsupported_basis_size_is_an_error_not_a_crash(spaces):
     phi = np.linalg.qr(rng.standard_normal((V.dim(), 209)))[0]
     with pytest.raises(FinromError):
         AffineROMFin(V, None, phi).forward_nine_param_reduced_batch(np.ones((2, 9)))
+
+
+def test_small_schedule_rejects_corrupt_levels(spaces):
+    """finrom_fom_set_small validates structure, pairs and the level property on the host (a row may only read rows of
+    lower levels): a corrupted schedule is an error code."""
+    import ctypes as C
+    from bayesianinferencedl_amd import _ffi
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    import bayesianinferencedl_amd.engine as E
+    if E.SMALL_MAX == 0:
+        pytest.skip("small-batch schedule disabled in this parametrisation")
+    lib = _ffi.lib()
+    real = lib.finrom_fom_set_small
+    seen = {}
+
+    def spy(h, dref):
+        d = dref._obj
+        n_lev = d.nlev_f
+        a, b = d.lev_rows_f[0], d.lev_rows_f[d.lev_ptr_f[n_lev] - 1]      # a leaf row and the root row
+        d.lev_rows_f[0], d.lev_rows_f[d.lev_ptr_f[n_lev] - 1] = b, a       # root in level 0: reads rows of higher levels
+        seen["levels"] = (real(h, C.byref(d)), lib.finrom_last_error())
+        d.lev_rows_f[0], d.lev_rows_f[d.lev_ptr_f[n_lev] - 1] = a, b
+        old = d.pair_b[0]
+        d.pair_b[0] = -5
+        seen["pair"] = real(h, C.byref(d))
+        d.pair_b[0] = old
+        return real(h, dref)
+    try:
+        lib.finrom_fom_set_small = spy
+        res = Fin(spaces(4)).forward_batch(np.full((3, 9), 1.0), params="nine")
+    finally:
+        lib.finrom_fom_set_small = real
+    assert seen["levels"][0] != 0 and b"levels" in seen["levels"][1]
+    assert seen["pair"] != 0
+    assert (np.asarray(res["info"]) == 0).all()
