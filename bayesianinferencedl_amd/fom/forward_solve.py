@@ -125,6 +125,14 @@ class Fin:
         g = self.gradient_batch(np.repeat(K, self.n_obs, axis=0), data, params=params)["grad"]
         return np.asarray(g).reshape(S, self.n_obs, -1)
 
+    def GN_hessian_action(self, k, u_2, data=None):
+        """Gauss-Newton Hessian action of J = 1/2 |B_obs w(k) - data|^2 on a direction u_2: (dq/dk)^T (dq/dk) u_2, from the
+        device Jacobian (`sensitivity`).  The reference's version (:372-394) assembles `exp(k)`-weighted incremental forms
+        although its forward model uses k itself (its own TODO, :243-263); this one is consistent with `forward` /
+        `gradient`.  `data` does not enter a Gauss-Newton Hessian and is accepted for call compatibility."""
+        Jac = self.sensitivity(k)
+        return Jac.T @ (Jac @ as_nodal(u_2))
+
     # ---- Tikhonov regulariser (:186-191).  The reference exposes UFL forms that callers assemble after assigning
     # solver._k (bayesian_inference/estimate_MAP.py:94-109); here they are evaluated for the current _k.
     gamma = 1e-6

@@ -338,6 +338,13 @@ def test_fom_sensitivity_and_regulariser(problems, spaces):
     for s in range(3):
         Js = fo.sensitivity(fo.nine_param_to_function(kap[s])) @ N9
         assert np.linalg.norm(Jb[s] - Js) < 1e-9 * np.linalg.norm(Js)
+    # Gauss-Newton Hessian action = J^T J u; also the derivative of the gradient along u where the residual vanishes
+    u = rng.standard_normal(prob.n)
+    Hu = fin.GN_hessian_action(Function(V, k), Function(V, u))
+    assert np.linalg.norm(Hu - Jo.T @ (Jo @ u)) < 1e-8 * np.linalg.norm(Hu)
+    data0 = fo.B_obs @ fo.forward(k)
+    fd_g = (fo.gradient(k + eps * u, data0) - fo.gradient(k - eps * u, data0)) / (2 * eps)
+    assert np.linalg.norm(Hu - fd_g) < 1e-5 * np.linalg.norm(fd_g)
     fin._k.assign(Function(V, k))
     assert abs(fin.reg - fo.reg(k)) < 1e-12 * abs(fo.reg(k))
     assert np.linalg.norm(fin.grad_reg - fo.grad_reg(k)) < 1e-12 * np.linalg.norm(fo.grad_reg(k))
