@@ -133,6 +133,21 @@ class Fin:
         Jac = self.sensitivity(k)
         return Jac.T @ (Jac @ as_nodal(u_2))
 
+    # ---- dense mass and stiffness matrices the reference keeps as attributes (:172-173; not used by the hot loop) ----------
+    @property
+    def M(self):
+        if getattr(self, "_M", None) is None:
+            cells, area = self.ops.mesh.cells, self.ops.cell_area
+            loc = (np.ones((3, 3)) + np.eye(3)) / 12.0                       # P1 mass matrix of a triangle / area
+            rows = np.repeat(cells, 3, axis=1).ravel(); cols = np.tile(cells, (1, 3)).ravel()
+            vals = (area[:, None, None] * loc[None, :, :]).ravel()
+            self._M = sp.coo_matrix((vals, (rows, cols)), shape=(self.dofs, self.dofs)).toarray()
+        return self._M
+
+    @property
+    def K(self):
+        return self._unit_stiffness().toarray()
+
     # ---- Tikhonov regulariser (:186-191).  The reference exposes UFL forms that callers assemble after assigning
     # solver._k (bayesian_inference/estimate_MAP.py:94-109); here they are evaluated for the current _k.
     gamma = 1e-6

@@ -146,6 +146,8 @@ def test_scalar_call_surface(problems, spaces):
     _, A_r_o, B_r_o, _ = ro.forward_nine_param_reduced(ro.subfin_avg_op(k), True)
     assert rel(solver_r._A_r, A_r_o) < 1e-12 and rel(solver_r._B_r[None, :], B_r_o[None, :]) < 1e-12
     assert rel(solver.subfin_avg_op(z), prob.S @ k) < 1e-13
+    # dense mass / stiffness attributes of the reference (fom :172-173): area 9, constants in the stiffness null space
+    assert abs(solver.M.sum() - 9.0) < 1e-12 and np.abs(solver.K @ np.ones(prob.n)).max() < 1e-12
     assert rel(solver_r.forward(z).vector()[:], ro.forward(k)) < TOL
     k5 = rng.uniform(0.1, 1.0, 5)
     assert rel(solver.forward_five_param(k5)[0].vector()[:], fo.forward_five_param(k5)) < TOL
