@@ -95,6 +95,24 @@ class ResBnFcModel:
         return m
 
 
+def load_dataset_avg_rom(load_prev=True, tr_size=6000, v_size=500, genrand=False, data_dir='../data', **gen_kwargs):
+    """Reader contract of the reference's training scripts (deep_learning/dl_model.py:19-36): conductivity fields and
+    QoI errors for training and validation, loaded from `<data_dir>/z_aff_avg_{tr,eval}.npy` /
+    `errors_aff_avg_{tr,eval}.npy` when present (and load_prev), otherwise generated on the device by
+    gen_affine_avg_rom_dataset (which writes the `*_avg_obs_3` files of its own, :102-110).
+    -> (z_train, errors_train, z_val, errors_val)."""
+    import os
+    from .generate_fin_dataset import gen_affine_avg_rom_dataset
+    out = []
+    for tag, size in (("tr", tr_size), ("eval", v_size)):
+        zf, ef = os.path.join(data_dir, f"z_aff_avg_{tag}.npy"), os.path.join(data_dir, f"errors_aff_avg_{tag}.npy")
+        if load_prev and os.path.isfile(zf) and os.path.isfile(ef):
+            out += [np.load(zf), np.load(ef)]
+        else:
+            out += list(gen_affine_avg_rom_dataset(size, genrand=genrand, out_dir=data_dir, **gen_kwargs))
+    return tuple(out)
+
+
 def res_bn_fc_model(n_layers, n_weights, input_shape=1446, output_shape=9, seed=0):
     """Constructor with the reference's argument meaning (activation / optimiser / learning rate dropped: inference only)."""
     return ResBnFcModel(input_shape, output_shape, n_layers, n_weights, seed)

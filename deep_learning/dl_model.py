@@ -1,1 +1,1 @@
-from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel, res_bn_fc_model  # noqa: F401
+from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel, load_dataset_avg_rom, res_bn_fc_model  # noqa: F401
