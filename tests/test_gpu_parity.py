@@ -427,3 +427,30 @@ def test_small_schedule_rejects_corrupt_levels(spaces):
     assert seen["levels"][0] != 0 and b"levels" in seen["levels"][1]
     assert seen["pair"] != 0
     assert (np.asarray(res["info"]) == 0).all()
+
+
+def test_sq_error_ops_value_and_gradient(problems, spaces):
+    """bayesian_inference/pymc_func_bayes_inverse.py:29-167: the misfit value-and-gradient callables behind the reference's
+    Theano operators, for the FOM, the ROM and the ROM + learned error, against the oracle."""
+    from bayesianinferencedl_amd.bayesian_inference.pymc_func_bayes_inverse import SqErrorOpFOM, SqErrorOpROM, SqErrorOpROMML
+    from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel
+    m = 4
+    prob = problems(m); V = spaces(m)
+    phi = oracle_basis(prob, 8)
+    rng = np.random.default_rng(12)
+    k_true = np.exp(0.3 * rng.standard_normal(prob.n))
+    model = ResBnFcModel(n_in=prob.n, n_out=9, n_layers=2, n_weights=10, seed=2)
+    fo = O.FinOracle(prob); ro = O.AffineROMOracle(prob, phi)
+    data = fo.B_obs @ fo.forward(k_true)
+    ro.set_data(data)
+    k = np.exp(0.3 * rng.standard_normal(prob.n))
+    for Op, want in ((SqErrorOpFOM, (0.5 * np.sum((fo.B_obs @ fo.forward(k) - data) ** 2), fo.gradient(k, data))),
+                     (SqErrorOpROM, tuple(reversed(ro.grad_reduced(k)))),
+                     (SqErrorOpROMML, tuple(reversed(O.grad_romml_oracle(ro, model, k))))):
+        op = Op(V, None, False, phi=phi, k_true=k_true, err_model=model)
+        assert np.linalg.norm(op._error_op.obs_data - data) < 1e-10 * np.linalg.norm(data)
+        out = [[None], [None]]
+        op.perform(None, [k], out)
+        assert abs(float(out[0][0]) - want[0]) < 1e-8 * abs(want[0])
+        assert np.linalg.norm(out[1][0] - want[1]) < 1e-6 * np.linalg.norm(want[1])
+        assert np.allclose(op.grad([k], [2.0])[0], 2.0 * out[1][0])
