@@ -698,7 +698,6 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
   if (!h || S < 0 || (S > 0 && (!theta || !data || !J || !g))) { set_error("rom_grad: bad argument"); return FINROM_ERR_ARG; }
   if (h->g_npairs == 0) { set_error("rom_grad: finrom_rom_set_gradient has not been called"); return FINROM_ERR_ARG; }
   const RomDev& d = h->d;
-  if (d.NB > 6) { set_error("rom_grad: basis size > 96 not supported yet"); return FINROM_ERR_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const size_t per_sample = ((size_t)d.rp * (d.rp + 1) / 2 + d.rp) * sizeof(double);
   int64_t chunk = std::max<int64_t>(4, (int64_t)(((size_t)16 << 30) / per_sample) / 4 * 4);
@@ -709,7 +708,9 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
     if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
     double* q = qoi_r ? qoi_r + s0 * d.n_obs : nullptr;
     if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
-    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, 1, info ? info + s0 : nullptr, st))) return rc;
+    // the factor of A_r: inside the projection kernel for r <= 96, by the blocked MFMA Cholesky kernel for wider bases
+    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, d.NB <= 6 ? 1 : 0, info ? info + s0 : nullptr, st))) return rc;
+    if (d.NB > 6 && (rc = launch_rom_chol_blocked(d, (double*)h->Ar.p, Sc, info ? info + s0 : nullptr, st))) return rc;
     RomGradArgs ga;
     ga.data = data + (data_per_sample ? s0 * d.n_obs : 0); ga.data_stride = data_per_sample ? d.n_obs : 0;
     ga.theta = theta + s0 * d.P; ga.J = J + s0; ga.g = g + s0 * d.P;

@@ -559,18 +559,30 @@ static int launch_solve_t(const RomDev& p, size_t lds, const double* Ar, const d
   return 0;
 }
 
+template <bool IN_LDS, int NSET>
+static int launch_grad_t(const RomDev& p, size_t lds, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
+                         int* info, const RomGradArgs& ga, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((rom_solve_kernel<IN_LDS, NSET, true, true>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r,
+                     (double*)nullptr, (double*)nullptr, info, ga);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_rom_grad(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
                     int* info, const RomGradArgs& ga, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  const size_t lds = ((size_t)p.rp * (p.rp + 1) / 2 + 3 * (size_t)p.rp + 64) * sizeof(double);
+  const size_t lds = ((p.solve_in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 3 * (size_t)p.rp + 64) * sizeof(double);
   const int nset = (p.rp + 63) / 64;
-  if (nset == 1) hipLaunchKernelGGL((rom_solve_kernel<true, 1, true, true>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r,
-                                    (double*)nullptr, (double*)nullptr, info, ga);
-  else hipLaunchKernelGGL((rom_solve_kernel<true, 2, true, true>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r,
-                          (double*)nullptr, (double*)nullptr, info, ga);
-  FR_HIP(hipGetLastError());
-  return 0;
+  if (!p.solve_in_lds) return launch_grad_t<false, 4>(p, lds, Ar, Br, S, w_r, qoi_r, info, ga, st);   // r > 176: factor in global memory
+  if (nset == 1) return launch_grad_t<true, 1>(p, lds, Ar, Br, S, w_r, qoi_r, info, ga, st);
+  if (nset == 2) return launch_grad_t<true, 2>(p, lds, Ar, Br, S, w_r, qoi_r, info, ga, st);
+  return launch_grad_t<true, 3>(p, lds, Ar, Br, S, w_r, qoi_r, info, ga, st);
 }
 
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,

@@ -216,7 +216,7 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S,
  * finrom_rom_set_gradient installs the host-precomputed blocks G_pi = (A_p Phi)^T (A_i Phi), one r x r matrix
  * per listed pair (p in 0..P with 0 = constant term, i in 0..P-1), each stored COLUMN by column.
  * finrom_rom_grad: theta [S x P], data [n_obs] (data_per_sample = 0) or [S x n_obs] (1) ->
- * J [S], g [S x P]; optional w_r [S x r], qoi_r [S x n_obs]; info as for finrom_rom_solve.  r <= 96. */
+ * J [S], g [S x P]; optional w_r [S x r], qoi_r [S x n_obs]; info as for finrom_rom_solve.  Any supported r (<= 208). */
 int finrom_rom_set_gradient(finrom_rom_t h, int32_t npairs, const int32_t* pair_p, const int32_t* pair_i,
                             const double* G);
 int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int32_t data_per_sample,

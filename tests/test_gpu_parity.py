@@ -163,7 +163,7 @@ def test_info_flags_non_spd(spaces):
     assert np.isnan(res["qoi"][1]).all() and np.isfinite(res["qoi"][[0, 2]]).all()
 
 
-@pytest.mark.parametrize("m,r", [(4, 8), (12, 80), (12, 50)])
+@pytest.mark.parametrize("m,r", [(4, 8), (12, 80), (12, 50), (12, 90), (12, 120), (12, 150), (12, 200)])
 def test_rom_adjoint_gradient_parity(problems, spaces, m, r):
     """AffineROMFin.grad_reduced (rom/averaged_affine_ROM.py:335-356) against the oracle restatement."""
     from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
