@@ -81,6 +81,8 @@ SIGNATURES = {
     "finrom_rom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "finrom_rom_set_gradient": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, c_i32p, c_f64p]),
+    "finrom_rom_set_gram": (C.c_int, [C.c_void_p, C.c_int32, c_i32p, c_i32p, c_f64p]),
+    "finrom_rom_set_projection": (C.c_int, [C.c_void_p, C.c_int32]),
     "finrom_rom_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 6),
     "finrom_subfin_avg": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "finrom_sampler_create": (C.c_int, [c_f64p, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -112,7 +114,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 4:
+        if L.finrom_version() != 5:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

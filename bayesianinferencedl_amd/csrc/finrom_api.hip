@@ -2,6 +2,7 @@
 #include "finrom_internal.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -85,6 +86,8 @@ struct finrom_rom_s {
   std::vector<void*> owned;
   Scratch Ar, Br, theta, qtmp;
   int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
+  RomGramDev gram;                     // offline/online form (finrom_rom_set_gram); gram.h is filled at create
+  int projection = FINROM_PROJECTION_DIRECT;
   hipStream_t side = nullptr;          // library-owned stream for the ROM half of finrom_solve_pairs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -614,7 +617,16 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   }
   if (rtv.empty()) { rtv.assign(4 * rp, 0.0); rpi.assign(4, 0); rf.assign(4, 0.0); }
 
+  // h_p = Psi_p^T F for the offline/online form of B_r
+  std::vector<double> hp((size_t)(a->P + 1) * rp, 0.0);
+  for (int i = 0; i < a->n; ++i) {
+    if (a->rhs[i] == 0.0) continue;
+    for (int t = a->row_ptr[i]; t < a->row_ptr[i + 1]; ++t)
+      for (int col = 0; col < r; ++col) hp[(size_t)a->term_p[t] * rp + col] += a->rhs[i] * a->term_val[(size_t)t * r + col];
+  }
+
   int rc = 0;
+  if (!rc) rc = up(h->owned, &h->gram.h, hp.data(), hp.size());
   if (d.n_chunks > 0) {
     if (!rc) rc = up(h->owned, &d.ch_nt, ch_nt.data(), ch_nt.size());
     if (!rc) rc = up(h->owned, &d.ch_nks, ch_nks.data(), ch_nks.size());
@@ -643,6 +655,68 @@ void finrom_rom_destroy(finrom_rom_t h) {
   delete h;
 }
 
+int finrom_rom_set_gram(finrom_rom_t h, int32_t npairs, const int32_t* pair_p, const int32_t* pair_q, const double* G) {
+  if (!h || npairs <= 0 || !pair_p || !pair_q || !G) { set_error("rom_set_gram: bad argument"); return FINROM_ERR_ARG; }
+  if (npairs > ROM_GRAM_MAX_PAIRS) { set_error("rom_set_gram: more than 64 pairs"); return FINROM_ERR_UNSUPPORTED; }
+  const RomDev& d = h->d;
+  const int r = d.r, R = d.rp, NB = d.NB;
+  for (int t = 0; t < npairs; ++t)
+    if (pair_p[t] < 0 || pair_q[t] > d.P || pair_p[t] > pair_q[t]) { set_error("rom_set_gram: invalid pair (need 0 <= p <= q <= P)"); return FINROM_ERR_ARG; }
+  for (int t = 0; t < npairs; ++t)
+    for (int u = 0; u < t; ++u)
+      if (pair_p[t] == pair_p[u] && pair_q[t] == pair_q[u]) { set_error("rom_set_gram: duplicate pair"); return FINROM_ERR_ARG; }
+  auto at = [&](int t, int i, int j) { return (i < r && j < r) ? G[((size_t)t * r + i) * r + j] : 0.0; };
+  for (int t = 0; t < npairs; ++t)
+    for (int i = 0; i < r; ++i)
+      for (int j = 0; j < i; ++j) {
+        const double x = at(t, i, j), y = at(t, j, i);
+        if (!(std::fabs(x - y) <= 1e-12 * (std::fabs(x) + std::fabs(y)) + 1e-300)) { set_error("rom_set_gram: block is not symmetric"); return FINROM_ERR_ARG; }
+      }
+  int rc = 0;
+  RomGramDev gm = h->gram;
+  if (!rc) rc = up(h->owned, &gm.pair_p, pair_p, npairs);
+  if (!rc) rc = up(h->owned, &gm.pair_q, pair_q, npairs);
+  if (NB <= 6) {       // tile images: lane (q, c), register g of tile (ti <= tj) holds entry (16 ti + q + 4 g, 16 tj + c)
+    const int NT = NB * (NB + 1) / 2;
+    std::vector<double> Gt((size_t)npairs * NT * 256, 0.0);
+    for (int t = 0; t < npairs; ++t) {
+      int tile = 0;
+      for (int ti = 0; ti < NB; ++ti)
+        for (int tj = ti; tj < NB; ++tj, ++tile)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int g = 0; g < 4; ++g)
+              Gt[(((size_t)t * NT + tile) * 64 + lane) * 4 + g] = at(t, 16 * ti + (lane >> 4) + 4 * g, 16 * tj + (lane & 15));
+    }
+    if (!rc) rc = up(h->owned, &gm.Gt, Gt.data(), Gt.size());
+  } else {             // packed upper triangle, row by row (= the lower triangle by columns the Cholesky kernels read)
+    const size_t np = (size_t)R * (R + 1) / 2;
+    std::vector<double> Gp((size_t)npairs * np, 0.0);
+    for (int t = 0; t < npairs; ++t)
+      for (int row = 0; row < r; ++row)
+        for (int col = row; col < r; ++col) Gp[t * np + (size_t)row * R - ((size_t)row * (row - 1)) / 2 + col - row] = at(t, row, col);
+    if (!rc) rc = up(h->owned, &gm.Gp, Gp.data(), Gp.size());
+  }
+  if (rc) return rc;
+  gm.npairs = npairs;
+  h->gram = gm;
+  return 0;
+}
+
+int finrom_rom_set_projection(finrom_rom_t h, int32_t mode) {
+  if (!h || (mode != FINROM_PROJECTION_DIRECT && mode != FINROM_PROJECTION_GRAM)) { set_error("rom_set_projection: bad argument"); return FINROM_ERR_ARG; }
+  if (mode == FINROM_PROJECTION_GRAM && h->gram.npairs == 0) { set_error("rom_set_projection: finrom_rom_set_gram has not been called"); return FINROM_ERR_ARG; }
+  h->projection = mode;
+  return 0;
+}
+
+// A_r, B_r (or, with factor > 0, the factor / the solution) by the form of the reduced operator the handle is set to
+static int rom_project(finrom_rom_t h, const double* theta, int64_t S, int factor, int* info, hipStream_t st,
+                       double* w_r = nullptr, double* qoi_r = nullptr) {
+  if (h->projection == FINROM_PROJECTION_GRAM)
+    return launch_rom_gram(h->d, h->gram, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r);
+  return launch_rom_proj(h->d, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r);
+}
+
 int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r, double* qoi_r, double* A_r,
                      double* B_r, int32_t* info, void* stream) {
   if (!h || S < 0 || (S > 0 && (!theta || (!qoi_r && h->d.n_obs > 0)))) { set_error("rom_solve: bad argument"); return FINROM_ERR_ARG; }
@@ -665,8 +739,8 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
     // as well: no packed factor in memory, no second kernel
     if (factor && d.NB <= 5 && A_r == nullptr && B_r == nullptr && getenv("FINROM_NO_FUSED_SOLVE") == nullptr &&
         getenv("FINROM_PROJ_LDS") == nullptr) factor = 2;
-    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, factor, info ? info + s0 : nullptr, st,
-                              w_r ? w_r + s0 * d.r : nullptr, qoi_r ? qoi_r + s0 * d.n_obs : nullptr))) return rc;
+    if ((rc = rom_project(h, theta + s0 * d.P, Sc, factor, info ? info + s0 : nullptr, st,
+                          w_r ? w_r + s0 * d.r : nullptr, qoi_r ? qoi_r + s0 * d.n_obs : nullptr))) return rc;
     if (factor == 2) continue;
     int factored = factor;
     if (want_factor && d.NB > 6) {                                     // wider bases: blocked MFMA Cholesky kernel
@@ -709,7 +783,7 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
     double* q = qoi_r ? qoi_r + s0 * d.n_obs : nullptr;
     if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
     // the factor of A_r: inside the projection kernel for r <= 96, by the blocked MFMA Cholesky kernel for wider bases
-    if ((rc = launch_rom_proj(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, d.NB <= 6 ? 1 : 0, info ? info + s0 : nullptr, st))) return rc;
+    if ((rc = rom_project(h, theta + s0 * d.P, Sc, d.NB <= 6 ? 1 : 0, info ? info + s0 : nullptr, st))) return rc;
     if (d.NB > 6 && (rc = launch_rom_chol_blocked(d, (double*)h->Ar.p, Sc, info ? info + s0 : nullptr, st))) return rc;
     RomGradArgs ga;
     ga.data = data + (data_per_sample ? s0 * d.n_obs : 0); ga.data_stride = data_per_sample ? d.n_obs : 0;

@@ -157,6 +157,17 @@ struct RomGradArgs {                      // adjoint-gradient stage of rom_solve
   double* J = nullptr; double* g = nullptr;                 // [S], [S x P]
   int npairs = 0; const int* pair_p = nullptr; const int* pair_i = nullptr; const double* Gt = nullptr;
 };
+// offline/online form of the reduced operator (finrom_rom_set_gram, rom_gram.hip)
+constexpr int ROM_GRAM_MAX_PAIRS = 64;
+struct RomGramDev {
+  int npairs = 0;
+  const int* pair_p = nullptr; const int* pair_q = nullptr;   // [npairs], 0 = the constant term
+  const double* Gt = nullptr;     // [npairs][NB(NB+1)/2][64][4]  tiles in the MFMA C/D register layout (r <= 96)
+  const double* Gp = nullptr;     // [npairs][rp(rp+1)/2]         packed upper triangle, row by row (r > 96)
+  const double* h = nullptr;      // [P+1][rp]                    h_p = Psi_p^T F
+};
+int launch_rom_gram(const RomDev& p, const RomGramDev& gm, const double* theta, int64_t S, double* Ar, double* Br, int factor,
+                    int* info, hipStream_t st, double* w_r = nullptr, double* qoi_r = nullptr);
 int launch_rom_grad(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
                     int* info, const RomGradArgs& ga, hipStream_t st);
 int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, hipStream_t st);

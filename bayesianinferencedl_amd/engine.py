@@ -248,6 +248,20 @@ class RomEngine:
               "finrom_rom_set_gradient")
         self._has_grad = True
 
+    def set_gram_blocks(self, pairs, G):
+        """pairs: list of (p, q), 0 <= p <= q <= P; G [npairs, r, r] symmetric blocks Psi_p^T Psi_q (+ transpose for p != q)
+        (finrom_rom_set_gram)."""
+        pp, pq = i32([p for p, _ in pairs]), i32([q for _, q in pairs])
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        check(lib().finrom_rom_set_gram(self._h, len(pairs), pp[1], pq[1], G.ctypes.data_as(_ffi.c_f64p)), "finrom_rom_set_gram")
+        self.gram_pairs = len(pairs)
+
+    def set_projection(self, mode):
+        """'direct' (per-sample psi^T psi on MFMA, the reference's contraction) or 'offline_online' (precomputed blocks)."""
+        code = {"direct": 0, "offline_online": 1}[mode]
+        check(lib().finrom_rom_set_projection(self._h, code), "finrom_rom_set_projection")
+        self.projection = mode
+
     def grad(self, theta, data):
         """theta [S, P], data [n_obs] or [S, n_obs] -> dict(J [S], g [S, P], w_r, qoi_r, info)."""
         b = _Batch(theta, self.P)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 4
+#define FINROM_ABI_VERSION 5
 
 typedef enum {
   FINROM_OK = 0,
@@ -207,6 +207,22 @@ void finrom_rom_destroy(finrom_rom_t h);
 int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S,
                      double* w_r, double* qoi_r, double* A_r, double* B_r,
                      int32_t* info, void* stream);
+
+/* ---- offline/online form of the reduced operator (opt-in) ------------------------------------------ *
+ * psi = A(theta) Phi = sum_p theta_p Psi_p (rom/averaged_affine_ROM.py:282-290; theta_0 = 1 for the Robin term), so
+ *   A_r = psi^T psi = sum_{p <= q} theta_p theta_q G_pq,  G_pq = Psi_p^T Psi_q + (p != q ? Psi_q^T Psi_p : 0),
+ *   B_r = psi^T F   = sum_p theta_p Psi_p^T F
+ * can be assembled from blocks computed once (the reference precomputes Psi_p = A_p Phi, :215-220, and contracts per
+ * sample, :291-297).  finrom_rom_set_gram installs the symmetric r x r blocks G_pq, row-major, one per listed pair
+ * 0 <= p <= q <= P (0 = constant term; pairs not listed are zero; at most 64 pairs); Psi_p^T F is derived from the
+ * descriptor at create.  finrom_rom_set_projection then selects which form finrom_rom_solve / _grad / finrom_solve_pairs
+ * use: FINROM_PROJECTION_DIRECT (default: the per-sample psi^T psi contraction on fp64 MFMA, what the reference
+ * executes) or FINROM_PROJECTION_GRAM.  Results agree to round-off (tests run both against the same oracle). */
+#define FINROM_PROJECTION_DIRECT 0
+#define FINROM_PROJECTION_GRAM 1
+int finrom_rom_set_gram(finrom_rom_t h, int32_t npairs, const int32_t* pair_p, const int32_t* pair_q,
+                        const double* G);
+int finrom_rom_set_projection(finrom_rom_t h, int32_t mode);
 
 /* ---- ROM adjoint gradient (AffineROMFin.grad_reduced, rom/averaged_affine_ROM.py:335-356) ---------- *
  * J = 1/2 |data - (B_obs Phi) w_r|^2 and its gradient with respect to the P affine parameters,
