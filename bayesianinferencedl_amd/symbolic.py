@@ -415,6 +415,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
         f_c0, f_ptr, f_idx, f_w = (np.asarray(a) for a in fused_asm)
     em = _Emitter(nnzL + 2 * n, pad_b=ZERO, chunk=fwd_chunk)
     done_chunk = np.zeros(n, np.int64)
+    y_nonzero = np.zeros(n, bool)     # rows of L y = F whose solution can be non-zero (F is zero except at the root nodes)
     remaining = ndeps.copy()
     eligible = [(-height[i], i) for i in range(n) if remaining[i] == 0]
     heapq.heapify(eligible)
@@ -459,8 +460,12 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
                 em.emit(OP_FINOFF, a=IV + j, b=slot if slot < cache_slots else -1, d=e, loads=(IV + j,), stores=(e,))
         if rhs_nonzero is None or rhs_nonzero[i]:
             em.emit(OP_YSET, d=i)
+            y_nonzero[i] = True
         for e in range(e0, e1 - 1):
             slot = e - e0
+            if not y_nonzero[ent_col[e]]:
+                continue          # y_k is structurally zero (no load below row k in the elimination tree): nothing to subtract
+            y_nonzero[i] = True
             yk = YV + ent_col[e]
             if slot < cache_slots:
                 em.emit(OP_FMA, a=yk, b=slot, loads=(yk,))
