@@ -182,6 +182,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   if (a->n_imm < 0 || (a->n_imm > 0 && !a->imm)) return bad("imm");
   {
     std::vector<int> stored(gsize, -10);
+    std::vector<char> slot_set(std::max(a->cache_slots, 1), 0);      // row-cache slots that have been written (FINOFF)
     auto need = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 2 <= c; };
     for (int t = 0; t < a->nops_fwd; ++t) {
       const int k = a->fwd_kind[t], A = a->fwd_a[t], B = a->fwd_b[t], D = a->fwd_d[t], c = t / a->fwd_chunk;
@@ -189,7 +190,10 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
       switch (k) {
         case 0: if ((A >= 0 && !need(A, c)) || A < -1 || B < 0 || B >= a->cache_slots + 2) return bad("forward FMA op"); break;
         case 3: case 4: if (!need(A, c)) return bad("forward LDX/FMAX op"); break;
-        case 5: if (!need(A, c) || D < 0 || D >= nnzL || B < -1 || B >= a->cache_slots) return bad("forward FINOFF op"); stored[D] = c; break;
+        case 5: if (!need(A, c) || D < 0 || D >= nnzL || B < -1 || B >= a->cache_slots) return bad("forward FINOFF op"); stored[D] = c;
+                if (B >= 0) slot_set[B] = 1;
+                break;
+        case 11: if (B < 0 || B >= a->cache_slots || D < 0 || D >= a->cache_slots || !slot_set[B] || !slot_set[D]) return bad("forward FMALL op"); break;
         case 6: if (D < 0 || D >= nnzL || B < 0 || B >= n) return bad("forward FINDIAG op"); stored[D] = c; stored[nnzL + B] = c; break;
         case 7: if (D < 0 || D >= n) return bad("forward YSET op"); break;
         case 9: if (a->xdim > FOM_MAX_FUSED_X || B < 0 || B >= a->xdim || D < 0 || D >= a->n_imm) return bad("forward XFMA op"); fused = 1; break;
@@ -234,15 +238,20 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   d.has_grad = 0; d.nchunks_res = 0;
   if (const char* ph = getenv("FINROM_FOM_PHASES")) d.debug_phases = atoi(ph);
   std::vector<int> fkb(a->nops_fwd), bkb(a->nops_bwd);
-  // device encoding of the forward stream: load offsets in bytes, the common
-  // multiply-add carries the LDS byte offset of its row-cache slot, every other op kind | (b+1) << 8, and one bit
-  // mask per chunk flags the slots that are NOT plain multiply-adds
-  std::vector<int> fa2(a->nops_fwd), fmask(a->nops_fwd / a->fwd_chunk, 0);
+  // device encoding of the forward stream: load offsets in bytes, the common multiply-adds (FMA, FMALL) carry the LDS
+  // byte offsets of their row-cache slots in kb and d, every other op kind | (b+1) << 8, and one bit mask per chunk flags
+  // the slots that are NOT plain multiply-adds
+  std::vector<int> fa2(a->nops_fwd), fd2(a->nops_fwd), fmask(a->nops_fwd / a->fwd_chunk, 0);
+  const bool noload = getenv("FINROM_FOM_NOLOAD") != nullptr;      // timing experiment: no operand fetches (results are garbage)
   for (int t = 0; t < a->nops_fwd; ++t) {
     // ops without a global operand (padding, fused-assembly ops) fetch from beyond the buffer's range: the hardware
     // bounds check returns 0 without touching memory (a real element could be uninitialised: 0 * NaN)
-    fa2[t] = a->fwd_a[t] < 0 ? 0x7FFFFFF0 : a->fwd_a[t] * 512;
-    if (a->fwd_kind[t] == 0) fkb[t] = a->fwd_b[t] * 512;
+    fa2[t] = (a->fwd_a[t] < 0 || noload) ? 0x7FFFFFF0 : a->fwd_a[t] * 512;
+    fd2[t] = a->fwd_d[t];
+    // the common multiply-add is acc -= rc[b] * (G[a] + rc[d']): FMA reads the ZERO slot as d', FMALL an out-of-range G[a]
+    // the common multiply-add is acc -= rc[b] * (G[a] + rc[d']): FMA reads the ZERO slot as d', FMALL an out-of-range G[a]
+    if (a->fwd_kind[t] == 0) { fkb[t] = a->fwd_b[t] * 512; fd2[t] = (a->cache_slots + 1) * 512; }
+    else if (a->fwd_kind[t] == 11) { fkb[t] = a->fwd_b[t] * 512; fd2[t] = a->fwd_d[t] * 512; }
     else { fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8); fmask[t / a->fwd_chunk] |= 1 << (t % a->fwd_chunk); }
   }
   for (int t = 0; t < a->nops_bwd; ++t) bkb[t] = a->bwd_kind[t] | ((a->bwd_b[t] + 1) << 8);
@@ -269,7 +278,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   if (fused && a->n_alist != 0) { finrom_fom_destroy(h); set_error("fom_create: a fused stream must come with n_alist = 0"); return FINROM_ERR_ARG; }
   if (!rc) rc = up(h->owned, &d.f_imm, a->imm, (size_t)a->n_imm);
   if (!rc) rc = up(h->owned, &d.f_kb, fkb.data(), fkb.size());
-  if (!rc) rc = up(h->owned, &d.f_d, a->fwd_d, a->nops_fwd);
+  if (!rc) rc = up(h->owned, &d.f_d, fd2.data(), fd2.size());
   if (!rc) rc = up(h->owned, &d.b_a, a->bwd_a, a->nops_bwd);
   if (!rc) rc = up(h->owned, &d.b_kb, bkb.data(), bkb.size());
   if (!rc) rc = up(h->owned, &d.b_d, a->bwd_d, a->nops_bwd);

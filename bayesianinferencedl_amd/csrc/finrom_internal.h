@@ -81,7 +81,7 @@ struct FomDev {
   const int* asm_rec_i; const double* asm_rec_d;       // [n_alist][8] / [n_alist][5] fixed-size assembly records
   const int* asm_idx; const double* asm_w;            // terms beyond the first four of an entry
   const double* rhs;
-  const int* f_a; const int* f_kb; const int* f_d;     // forward stream: load byte offset, LDS byte offset (FMA) or kind | (b+1) << 8, d
+  const int* f_a; const int* f_kb; const int* f_d;     // forward stream: load byte offset, LDS byte offset of rc[b] (FMA, FMALL) or kind | (b+1) << 8, d (FMA / FMALL: LDS byte offset of the second LDS operand)
   const double* f_imm;                                 // immediates of the fused-assembly ops
   int fused;                                           // the forward stream assembles A itself (x in LDS, no pre-pass)
   const int* f_mask;                                   // per chunk: bit u set = slot u is not a plain multiply-add

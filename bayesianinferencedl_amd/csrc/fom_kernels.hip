@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void fom_assemble_kernel(FomDev p, const int* 
 // Global operands of chunk c+1 are in flight while chunk c executes (double-buffered in
 // registers); the op descriptors themselves are sequential scalar loads.
 // ---------------------------------------------------------------------------------------
-enum { F_FMA = 0, F_LDX = 3, F_FMAX = 4, F_FINOFF = 5, F_FINDIAG = 6, F_YSET = 7, F_FINY = 8, F_XFMA = 9, F_CADD = 10 };
+enum { F_FMA = 0, F_LDX = 3, F_FMAX = 4, F_FINOFF = 5, F_FINDIAG = 6, F_YSET = 7, F_FINY = 8, F_XFMA = 9, F_CADD = 10, F_FMALL = 11 };
 enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
 
 // The op arrays are separate __restrict__ kernel parameters on purpose: only then can the compiler
@@ -146,6 +146,10 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(gres, lane8, byte_off, 0));
   };
   const char* rcb = reinterpret_cast<const char*>(rowc) + lane8;
+  // FINROM_FOM_PHASES bits 4 / 5 (timing experiments only, results are garbage): FINOFF does not store to global memory /
+  // every op takes the multiply-add path
+  const int xmask = (p.debug_phases & 32) ? 0 : -1;
+  const bool nostore = p.debug_phases & 16;
 
 #define VM_LOAD1(buf, c)                                                      \
   _Pragma("unroll") for (int u = 0; u < FCH; ++u) buf[u] = ldgb(A[(c) * FCH + u]);
@@ -167,8 +171,10 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   _Pragma("unroll") for (int u = 0; u < FCH; ++u) nxt[u] = ldgb(an[u]);       \
   _Pragma("unroll") for (int u = 0; u < FCH; ++u) {                           \
     const double ld = buf[u];                                                 \
-    if (__builtin_expect(!(msk & (1 << u)), 1)) {                             \
-      acc = fma(-*reinterpret_cast<const double*>(rcb + kbv[u]), ld, acc);   /* also "acc = A_e" (NEG1) and padding (ZERO) */ \
+    if (__builtin_expect(!(msk & xmask & (1 << u)), 1)) {                     \
+      /* acc -= rc[b] * (G[a] + rc[d]): one of the two is exactly zero (FMA: d = the ZERO slot; FMALL: a out of range); */ \
+      /* also "acc = A_e" (b = NEG1) and padding (b = ZERO) */                 \
+      acc = fma(-*reinterpret_cast<const double*>(rcb + kbv[u]), ld + *reinterpret_cast<const double*>(rcb + dv[u]), acc); \
     } else {                                                                  \
       const int kb = kbv[u];                                                  \
       const int kind = kb & 255, b = (kb >> 8) - 1;                           \
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
         case F_FMAX: acc = fma(-rc[S_XREG * 64], ld, acc); break;             \
         case F_FINOFF: {                                                      \
           const double l = acc * ld;                                          \
-          Gs[(int64_t)d * 64 + lane] = l;                                     \
+          if (!nostore) Gs[(int64_t)d * 64 + lane] = l;                        \
           if (b >= 0) rc[b * 64] = l;                                         \
           acc = 0.0;                                                          \
         } break;                                                              \

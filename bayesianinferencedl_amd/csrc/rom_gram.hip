@@ -15,39 +15,12 @@
 
 namespace finrom {
 
+// everything after the tiles of A_r are complete (same steps as the projection kernel's epilogue)
 template <int NB>
-__global__ __launch_bounds__(256, 2) void rom_gram_kernel(RomDev p, RomGramDev gm, const double* __restrict__ theta, int64_t S,
-                                                       double* __restrict__ Ar, double* __restrict__ Br, int factor,
-                                                       int* __restrict__ info, double* __restrict__ w_r,
-                                                       double* __restrict__ qoi_r) {
-  constexpr int NT = NB * (NB + 1) / 2;
-  __shared__ double th[4][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t s = (int64_t)blockIdx.x * 4 + wave;
-  if (s >= S) return;                       // no block-wide barrier below
-  if (lane == 0) th[wave][0] = 1.0;
-  if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
-  __builtin_amdgcn_wave_barrier();
-  const double* thw = th[wave];
+__device__ __forceinline__ void gram_finish(const RomDev& p, const RomGramDev& gm, const double* thw, int64_t s, int lane,
+                                            d4 (&acc)[NB * (NB + 1) / 2], double* __restrict__ Ar, double* __restrict__ Br,
+                                            int factor, int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r) {
   const int q = lane >> 4, c = lane & 15;
-
-  d4 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-  // tile images [pair][tile][lane] of 4 doubles: one 32-byte load per lane, tile and pair, 2 KiB contiguous per wave
-  const d4* __restrict__ G = reinterpret_cast<const d4*>(gm.Gt) + lane;
-#pragma unroll 1
-  for (int pr = 0; pr < gm.npairs; ++pr) {
-    const double cf = thw[gm.pair_p[pr]] * thw[gm.pair_q[pr]];
-    const d4* __restrict__ Gp = G + (int64_t)pr * NT * 64;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const d4 g = Gp[t * 64];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[t][k] = fma(cf, g[k], acc[t][k]);
-    }
-  }
-
   int bad = 0;
   if (factor) {      // A_r = U^T U in registers; what is written below is then U^T (= L, packed by columns)
     bad = chol_tiles<NB>(acc, q, c, p.r);
@@ -103,6 +76,58 @@ __global__ __launch_bounds__(256, 2) void rom_gram_kernel(RomDev p, RomGramDev g
         }
     }
   }
+}
+
+// NS samples per wave: a tile image of G is loaded once and applied to NS accumulator sets (the kernel's memory traffic is
+// the G tiles, npairs * NB(NB+1)/2 * 2 KiB per wave from L2, and it runs beside the HBM-bound FOM interpreter); the
+// factorisations and substitutions then run one sample after the other.  NS = 2 only where both accumulator sets and the
+// factorisation fit 256 VGPRs (r <= 48): at r = 80 it needs 328 registers = one wave per SIMD, measured 8.9 ms per 100k
+// samples stand-alone against 4.8 ms for NS = 1 at two waves per SIMD.
+template <int NB, int NS>
+__global__ __launch_bounds__(256, 2) void rom_gram_kernel(RomDev p, RomGramDev gm, const double* __restrict__ theta, int64_t S,
+                                                          double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                                          int* __restrict__ info, double* __restrict__ w_r,
+                                                          double* __restrict__ qoi_r) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  __shared__ double th[4][NS][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * NS;
+  if (s0 >= S) return;                      // no block-wide barrier below
+  int64_t sidx[NS];
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    sidx[u] = s0 + u < S ? s0 + u : S - 1;  // a ragged tail repeats the last sample (same values stored twice)
+    if (lane == 0) th[wave][u][0] = 1.0;
+    if (lane < p.P) th[wave][u][lane + 1] = theta[sidx[u] * p.P + lane];
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  d4 acc[NS][NT];
+#pragma unroll
+  for (int u = 0; u < NS; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[u][t] = (d4){0.0, 0.0, 0.0, 0.0};
+  // tile images [pair][tile][lane] of 4 doubles: one 32-byte load per lane, tile and pair, 2 KiB contiguous per wave
+  const d4* __restrict__ G = reinterpret_cast<const d4*>(gm.Gt) + lane;
+#pragma unroll 1
+  for (int pr = 0; pr < gm.npairs; ++pr) {
+    const int pp = gm.pair_p[pr], pq = gm.pair_q[pr];
+    double cf[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) cf[u] = th[wave][u][pp] * th[wave][u][pq];
+    const d4* __restrict__ Gp = G + (int64_t)pr * NT * 64;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const d4 g = Gp[t * 64];
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[u][t][k] = fma(cf[u], g[k], acc[u][t][k]);
+    }
+  }
+  gram_finish<NB>(p, gm, th[wave][0], sidx[0], lane, acc[0], Ar, Br, factor, info, w_r, qoi_r);
+  if constexpr (NS > 1) gram_finish<NB>(p, gm, th[wave][1], sidx[1], lane, acc[1], Ar, Br, factor, info, w_r, qoi_r);
+  static_assert(NS <= 2, "one call per sample, written out so that the accumulators stay in registers");
 }
 
 // A_r for wide bases: grid (sample groups of 32, chunks of 256 packed entries).  Workgroups that run together share a chunk
@@ -161,10 +186,11 @@ int launch_rom_gram(const RomDev& p, const RomGramDev& gm, const double* theta, 
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_PROJ, st);
   if (p.NB <= 6) {
-    const dim3 grid((unsigned)((S + 3) / 4)), block(256);
+    const dim3 block(256);
     switch (p.NB) {
-#define FR_ONE(N) case N: hipLaunchKernelGGL(rom_gram_kernel<N>, grid, block, 0, st, p, gm, theta, S, Ar, Br, factor, info, w_r, qoi_r); break;
-      FR_ONE(1) FR_ONE(2) FR_ONE(3) FR_ONE(4) FR_ONE(5) FR_ONE(6)
+#define FR_ONE(N, NS) case N: hipLaunchKernelGGL((rom_gram_kernel<N, NS>), dim3((unsigned)((S + 4 * NS - 1) / (4 * NS))), block, 0, st, p, gm, \
+                                                 theta, S, Ar, Br, factor, info, w_r, qoi_r); break;
+      FR_ONE(1, 2) FR_ONE(2, 2) FR_ONE(3, 2) FR_ONE(4, 1) FR_ONE(5, 1) FR_ONE(6, 1)
 #undef FR_ONE
     }
   } else {

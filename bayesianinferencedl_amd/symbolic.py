@@ -12,6 +12,8 @@ so Cholesky computes the same w.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -348,6 +350,8 @@ OP_FMA, OP_LDX, OP_FMAX, OP_FINOFF, OP_FINDIAG, OP_YSET, OP_FINY = 0, 3, 4, 5, 6
 #   XFMA acc += imm[d] * x[b]      CADD acc += imm[d]
 # instead of being fetched from the pre-pass's output ("acc = A_e" FMA against the NEG1 slot)
 OP_XFMA, OP_CADD = 9, 10
+# both operands in LDS: acc -= rc[b] * rc[d] (the row cache is a ring: entries of recently finished rows are still in it)
+OP_FMALL = 11
 # a row entry beyond the LDS row cache is fetched like any other operand: LDX x = G[a]; FMAX acc -= x * G[a]
 OPB_NOP, OPB_WFMA, OPB_WSET, OPB_WFIN = 0, 1, 3, 5
 
@@ -407,15 +411,43 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
         par = plan.parent[i]
         height[i] = 0 if par < 0 else height[par] + (row_ptr[par + 1] - row_ptr[par])
     import heapq
+    if os.environ.get("FINROM_FWD_ORDER", "postorder") == "postorder":
+        # rows in postorder of the elimination tree (a row right after its subtree: the L_jk it reads were
+        # written recently); a row that would need padding yields to the next ready row in postorder
+        kids = [[] for _ in range(n)]
+        roots = []
+        for i in range(n):
+            (roots if plan.parent[i] < 0 else kids[plan.parent[i]]).append(i)
+        size = np.ones(n, np.int64)
+        for i in range(n):
+            if plan.parent[i] >= 0:
+                size[plan.parent[i]] += size[i]
+        po = np.zeros(n, np.int64); cnt = 0
+        stack = [(r0, False) for r0 in sorted(roots, key=lambda v: -size[v])][::-1]
+        while stack:
+            v, seen = stack.pop()
+            if seen:
+                po[v] = cnt; cnt += 1
+                continue
+            stack.append((v, True))
+            for c in sorted(kids[v], key=lambda u: size[u]):       # pushed small first -> the largest subtree is visited first
+                stack.append((c, False))
+        height = -po
 
     # ---------------- forward: factorisation + L y = F -----------------------------------
     NEG1, ZERO = cache_slots, cache_slots + 1
     imm = []
     if fused_asm is not None:
         f_c0, f_ptr, f_idx, f_w = (np.asarray(a) for a in fused_asm)
-    em = _Emitter(nnzL + 2 * n, pad_b=ZERO, chunk=fwd_chunk)
+    fwd_dist = int(os.environ.get("FINROM_FWD_DIST", "2"))
+    em = _Emitter(nnzL + 2 * n, pad_b=ZERO, chunk=fwd_chunk, distance=fwd_dist)
     done_chunk = np.zeros(n, np.int64)
     y_nonzero = np.zeros(n, bool)     # rows of L y = F whose solution can be non-zero (F is zero except at the root nodes)
+    # The LDS row cache is a RING: a row takes the next len(row) slots, so the entries of the rows finished just before it
+    # are still there, and a product L_ik L_jk whose L_jk is among them needs no global operand (OP_FMALL) -- and no
+    # producer -> consumer distance either.  In postorder the previous row is usually a child of the current one.
+    ring = os.environ.get("FINROM_FWD_RING", "1") != "0"
+    slot_of, slot_owner, ring_head = {}, [-1] * cache_slots, 0
     remaining = ndeps.copy()
     eligible = [(-height[i], i) for i in range(n) if remaining[i] == 0]
     heapq.heapify(eligible)
@@ -428,7 +460,9 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
             heapq.heappush(eligible, (nh, i))
         if eligible:
             _, i = heapq.heappop(eligible)
-            ready = max([done_chunk[j] + 2 for j in rows_cols[i]], default=0)
+            # only rows whose entries have to come from global memory constrain the start (a row still in the ring does not)
+            ready = max([done_chunk[j] + fwd_dist for j in rows_cols[i]
+                         if not (ring and all(int(e) in slot_of for e in range(row_ptr[j], row_ptr[j + 1] - 1)))], default=0)
             if ready > cur and (eligible or (waiting and waiting[0][0] < ready)):
                 heapq.heappush(waiting, (ready, -height[i], i))
                 continue
@@ -436,6 +470,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
             _, _, i = heapq.heappop(waiting)
         order.append(i)
         e0, e1 = row_ptr[i], row_ptr[i + 1]
+        my_slot = {}                                  # entries of THIS row that sit in the LDS row cache -> slot
         for e in range(e0, e1):
             j = ent_col[e]
             if plan.a_ent[e] >= 0 and fused_asm is not None:
@@ -447,8 +482,10 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
                 em.emit(OP_FMA, a=e, b=NEG1, loads=(e,))              # acc = 0 - (-1) * A_e
             for q in range(pair_ptr[e], pair_ptr[e + 1]):
                 pa, pb = int(plan.pair_a[q]), int(plan.pair_b[q])
-                slot = pa - e0
-                if slot < cache_slots:
+                slot = my_slot.get(pa, -1)
+                if slot >= 0 and pb in slot_of:
+                    em.emit(OP_FMALL, b=slot, d=slot_of[pb])           # L_jk of a recently finished row: still in the ring
+                elif slot >= 0:
                     em.emit(OP_FMA, a=pb, b=slot, loads=(pb,))
                 else:
                     em.emit(OP_LDX, a=pa, loads=(pa,))
@@ -456,18 +493,27 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
             if e == e1 - 1:
                 em.emit(OP_FINDIAG, b=i, d=e, stores=(e, IV + i))
             else:
-                slot = e - e0
-                em.emit(OP_FINOFF, a=IV + j, b=slot if slot < cache_slots else -1, d=e, loads=(IV + j,), stores=(e,))
+                slot = -1
+                if e - e0 < cache_slots:              # (a row longer than the cache keeps its first cache_slots entries)
+                    if ring:
+                        slot = ring_head; ring_head = (ring_head + 1) % cache_slots
+                        if slot_owner[slot] >= 0:
+                            slot_of.pop(slot_owner[slot], None)
+                        slot_owner[slot] = int(e); slot_of[int(e)] = slot
+                    else:
+                        slot = int(e - e0)
+                    my_slot[int(e)] = slot
+                em.emit(OP_FINOFF, a=IV + j, b=slot, d=e, loads=(IV + j,), stores=(e,))
         if rhs_nonzero is None or rhs_nonzero[i]:
             em.emit(OP_YSET, d=i)
             y_nonzero[i] = True
         for e in range(e0, e1 - 1):
-            slot = e - e0
+            slot = my_slot.get(int(e), -1)
             if not y_nonzero[ent_col[e]]:
                 continue          # y_k is structurally zero (no load below row k in the elimination tree): nothing to subtract
             y_nonzero[i] = True
             yk = YV + ent_col[e]
-            if slot < cache_slots:
+            if slot >= 0:
                 em.emit(OP_FMA, a=yk, b=slot, loads=(yk,))
             else:
                 em.emit(OP_LDX, a=e, loads=(e,))
@@ -494,6 +540,8 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
         par = plan.parent[i]
         if par >= 0:
             depth[par] = max(depth[par], depth[i] + 1 + (col_ptr[i + 1] - col_ptr[i]))
+    if os.environ.get("FINROM_FWD_ORDER", "postorder") == "postorder" and os.environ.get("FINROM_BWD_ORDER", "rpo") == "rpo":
+        depth = po.copy()                     # reverse postorder: a row right after its parent's subtree prefix
     done_b = np.zeros(n, np.int64)
     remaining = ndeps_b.copy()
     eligible = [(-depth[i], i) for i in range(n) if remaining[i] == 0]
@@ -614,6 +662,7 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots, x=None):
                     elif k == OPB_WFIN: G[d[t]] = acc * ld
                 else:
                     if k == OP_FMA: acc -= rc[b[t]] * ld
+                    elif k == OP_FMALL: acc -= rc[b[t]] * rc[d[t]]
                     elif k == OP_LDX: xreg = ld
                     elif k == OP_FMAX: acc -= xreg * ld
                     elif k == OP_FINOFF:

@@ -89,7 +89,7 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
  * lane = sample) fetches the global operands of chunk c+1 (fwd_chunk = 8 or 16 ops) before it executes chunk c,
  * so the host must order/pad the forward stream such that a value stored in chunk c is not loaded
  * before chunk c+2 (the backward stream is fetched chunk by chunk: not before c+1); checked at create.  Ops (kind, a, b, d), acc = per-sample accumulator,
- * rc = the LDS cache of the row being eliminated (cache_slots entries):
+ * rc = the LDS row cache (cache_slots entries; holds the row being eliminated and whatever the host left in the other slots):
  *   forward  0 FMA acc -= rc[b]*G[a]   (rc[cache_slots] == -1 and rc[cache_slots+1] == 0 are constants:
  *                  "acc = A_e" is an FMA against the first, padding an FMA against the second with a = -1)
  *            3 LDX x = G[a] | 4 FMAX acc -= x*G[a]   (a row entry that does not fit the LDS cache)
@@ -98,6 +98,9 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
  *            7 YSET acc = rhs[d] | 8 FINY G[d] = acc*inv; acc = 0
  *            9 XFMA acc += imm[d]*x[b] | 10 CADD acc += imm[d]   (fused affine assembly, xdim <= 16: the stream builds
  *                  A_e = c0_e + sum_t w_t x[idx_t] itself, x sits in LDS, and there is no assembly pre-pass: n_alist = 0)
+ *           11 FMALL acc -= rc[b]*rc[d]   (both operands in LDS: the host may allocate the slots of rc as a ring, so that
+ *                  the entries of the rows finished just before the current one are still there; slots must have been
+ *                  written by an earlier FINOFF.  No global operand, hence no chunk distance to respect.)
  *   backward 0 NOP | 1 WFMA acc -= G[a]*G[b] | 3 WSET acc = G[a] | 5 WFIN G[d] = acc*G[a]
  */
 typedef struct {
