@@ -145,6 +145,10 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   auto ldgb = [&](int byte_off) -> double {      // forward stream: offsets are pre-scaled on the host
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(gres, lane8, byte_off, 0));
   };
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto stg = [&](double v, int e) {             // G[e] = v for this lane
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), gres, lane8, e * 512, 0);
+  };
   const char* rcb = reinterpret_cast<const char*>(rowc) + lane8;
   // FINROM_FOM_PHASES bits 4 / 5 (timing experiments only, results are garbage): FINOFF does not store to global memory /
   // every op takes the multiply-add path
@@ -179,29 +183,32 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
       const int kb = kbv[u];                                                  \
       const int kind = kb & 255, b = (kb >> 8) - 1;                           \
       const int d = dv[u];                                                    \
-      switch (kind) {                                                         \
-        case F_LDX: rc[S_XREG * 64] = ld; break;   /* row entry beyond the LDS cache */ \
-        case F_FMAX: acc = fma(-rc[S_XREG * 64], ld, acc); break;             \
-        case F_FINOFF: {                                                      \
-          const double l = acc * ld;                                          \
-          if (!nostore) Gs[(int64_t)d * 64 + lane] = l;                        \
-          if (b >= 0) rc[b * 64] = l;                                         \
-          acc = 0.0;                                                          \
-        } break;                                                              \
-        case F_FINDIAG: {                                                     \
-          if (!(acc > 0.0)) rc[S_BAD * 64] = 1.0;                             \
-          const double t = sqrt(acc);                                         \
-          const double inv = 1.0 / t;                                         \
-          Gs[(int64_t)d * 64 + lane] = t;                                     \
-          Gs[(int64_t)(p.nnzL + b) * 64 + lane] = inv;                        \
-          rc[S_INV * 64] = inv;                                               \
-          acc = 0.0;                                                          \
-        } break;                                                              \
-        case F_YSET: acc = rhs[d]; break;                                     \
-        case F_XFMA: acc = fma(fImm[d], rc[(S_X0 + b) * 64], acc); break;   /* fused assembly: A_e += w * x_b */ \
-        case F_CADD: acc += fImm[d]; break;                                   \
-        case F_FINY: Gs[(int64_t)d * 64 + lane] = acc * rc[S_INV * 64]; acc = 0.0; break; \
-        default: break;                                                       \
+      /* tested in order of frequency; stores are buffer stores (descriptor + SGPR element offset, like the loads) */ \
+      if (kind == F_FINOFF) {                                                 \
+        const double l = acc * ld;                                            \
+        if (!nostore) stg(l, d);                                              \
+        if (b >= 0) rc[b * 64] = l;                                           \
+        acc = 0.0;                                                            \
+      } else if (kind == F_XFMA) {                                            \
+        acc = fma(fImm[d], rc[(S_X0 + b) * 64], acc);     /* fused assembly: A_e += w * x_b */ \
+      } else if (kind == F_FMAX) {                                            \
+        acc = fma(-rc[S_XREG * 64], ld, acc);                                 \
+      } else if (kind == F_LDX) {                                             \
+        rc[S_XREG * 64] = ld;                              /* row entry beyond the LDS cache */ \
+      } else if (kind == F_CADD) {                                            \
+        acc += fImm[d];                                                       \
+      } else if (kind == F_FINDIAG) {                                         \
+        if (!(acc > 0.0)) rc[S_BAD * 64] = 1.0;                               \
+        const double t = sqrt(acc);                                           \
+        const double inv = 1.0 / t;                                           \
+        stg(t, d);                                                            \
+        stg(inv, p.nnzL + b);                                                 \
+        rc[S_INV * 64] = inv;                                                 \
+        acc = 0.0;                                                            \
+      } else if (kind == F_FINY) {                                            \
+        stg(acc * rc[S_INV * 64], d); acc = 0.0;                              \
+      } else if (kind == F_YSET) {                                            \
+        acc = rhs[d];                                                         \
       }                                                                       \
     }                                                                         \
   }

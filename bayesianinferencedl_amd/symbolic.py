@@ -436,7 +436,14 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
 
     # ---------------- forward: factorisation + L y = F -----------------------------------
     NEG1, ZERO = cache_slots, cache_slots + 1
-    imm = []
+    imm, imm_pos = [], {}
+
+    def imm_index(v):
+        # a P1 stiffness on a lattice has a few dozen distinct weights: one small table that stays in the scalar cache
+        v = float(v)
+        if v not in imm_pos:
+            imm_pos[v] = len(imm); imm.append(v)
+        return imm_pos[v]
     if fused_asm is not None:
         f_c0, f_ptr, f_idx, f_w = (np.asarray(a) for a in fused_asm)
     fwd_dist = int(os.environ.get("FINROM_FWD_DIST", "2"))
@@ -475,9 +482,9 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
             j = ent_col[e]
             if plan.a_ent[e] >= 0 and fused_asm is not None:
                 if f_c0[e] != 0.0:
-                    em.emit(OP_CADD, d=len(imm)); imm.append(float(f_c0[e]))
+                    em.emit(OP_CADD, d=imm_index(f_c0[e]))
                 for t in range(f_ptr[e], f_ptr[e + 1]):
-                    em.emit(OP_XFMA, b=int(f_idx[t]), d=len(imm)); imm.append(float(f_w[t]))
+                    em.emit(OP_XFMA, b=int(f_idx[t]), d=imm_index(f_w[t]))
             elif plan.a_ent[e] >= 0:
                 em.emit(OP_FMA, a=e, b=NEG1, loads=(e,))              # acc = 0 - (-1) * A_e
             for q in range(pair_ptr[e], pair_ptr[e + 1]):
