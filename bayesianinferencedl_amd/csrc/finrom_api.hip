@@ -204,7 +204,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
       if (t >= a->nops_fwd - 2 * a->fwd_chunk && (k != 0 || B != a->cache_slots + 1)) return bad("forward stream tail (must be padding)");
     }
     std::fill(stored.begin(), stored.end(), -10);
-    auto need1 = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 1 <= c; };   // backward: fetched per chunk
+    auto need1 = [&](int g, int c) { return g >= 0 && g < gsize && stored[g] + 2 <= c; };   // backward: same look-ahead as forward
     for (int t = 0; t < a->nops_bwd; ++t) {
       const int k = a->bwd_kind[t], A = a->bwd_a[t], B = a->bwd_b[t], D = a->bwd_d[t], c = t / VM_CHUNK;
       if (A < -1 || A >= gsize || B < -1 || B >= gsize) return bad("backward op operand index");
@@ -254,7 +254,15 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
     else if (a->fwd_kind[t] == 11) { fkb[t] = a->fwd_b[t] * 512; fd2[t] = a->fwd_d[t] * 512; }
     else { fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8); fmask[t / a->fwd_chunk] |= 1 << (t % a->fwd_chunk); }
   }
-  for (int t = 0; t < a->nops_bwd; ++t) bkb[t] = a->bwd_kind[t] | ((a->bwd_b[t] + 1) << 8);
+  // backward stream on the device: byte offsets of both operands (out of range = no operand: the fetch returns 0 without
+  // touching memory) and kind | d << 8
+  std::vector<int> ba2(a->nops_bwd), bb2(a->nops_bwd);
+  for (int t = 0; t < a->nops_bwd; ++t) {
+    const int k = a->bwd_kind[t];
+    ba2[t] = (k == 0 || a->bwd_a[t] < 0) ? 0x7FFFFFF0 : a->bwd_a[t] * 512;
+    bb2[t] = (k != 1 || a->bwd_b[t] < 0) ? 0x7FFFFFF0 : a->bwd_b[t] * 512;
+    bkb[t] = k | ((k == 5 ? a->bwd_d[t] : 0) << 8);
+  }
   int rc = 0;
   const int nobsnz = a->n_obs > 0 ? a->obs_ptr[a->n_obs] : 0;
   // assembly records: {entry, idx0..3, first/last of the remaining terms, 0} and {c0, w0..3}; unused slots
@@ -279,9 +287,9 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   if (!rc) rc = up(h->owned, &d.f_imm, a->imm, (size_t)a->n_imm);
   if (!rc) rc = up(h->owned, &d.f_kb, fkb.data(), fkb.size());
   if (!rc) rc = up(h->owned, &d.f_d, fd2.data(), fd2.size());
-  if (!rc) rc = up(h->owned, &d.b_a, a->bwd_a, a->nops_bwd);
-  if (!rc) rc = up(h->owned, &d.b_kb, bkb.data(), bkb.size());
-  if (!rc) rc = up(h->owned, &d.b_d, a->bwd_d, a->nops_bwd);
+  if (!rc) rc = up(h->owned, &d.b_a, ba2.data(), ba2.size());
+  if (!rc) rc = up(h->owned, &d.b_b, bb2.data(), bb2.size());
+  if (!rc) rc = up(h->owned, &d.b_kd, bkb.data(), bkb.size());
   if (!rc) rc = up(h->owned, &d.obs_ptr, a->obs_ptr, a->n_obs + 1);
   if (!rc) rc = up(h->owned, &d.obs_idx, a->obs_idx, nobsnz);
   if (!rc) rc = up(h->owned, &d.obs_w, a->obs_w, nobsnz);

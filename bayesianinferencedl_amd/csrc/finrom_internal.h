@@ -85,7 +85,7 @@ struct FomDev {
   const double* f_imm;                                 // immediates of the fused-assembly ops
   int fused;                                           // the forward stream assembles A itself (x in LDS, no pre-pass)
   const int* f_mask;                                   // per chunk: bit u set = slot u is not a plain multiply-add
-  const int* b_a; const int* b_kb; const int* b_d;     // backward stream
+  const int* b_a; const int* b_b; const int* b_kd;     // backward stream: byte offsets of the two operands, kind | d << 8
   const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
   // adjoint gradient (finrom_fom_set_gradient); the value vector then has a 4th region v at nnzL + 2n
   int has_grad, nchunks_res;

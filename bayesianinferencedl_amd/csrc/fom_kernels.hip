@@ -107,13 +107,10 @@ enum { B_NOP = 0, B_WFMA = 1, B_WSET = 3, B_WFIN = 5 };
 // s_waitcnt vmcnt(0) drains the operand prefetch on every op.
 template <int FCH>      // FCH = ops per prefetch chunk of the forward stream
 __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __restrict__ fA, const int* __restrict__ fKB,
-                                                    const int* __restrict__ fD, const int* __restrict__ fM, const int* __restrict__ bA,
-                                                    const int* __restrict__ bKB, const int* __restrict__ bD,
-                                                    const double* __restrict__ rhs, const int* __restrict__ obs_ptr,
-                                                    const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
-                                                    const double* __restrict__ fImm, const double* __restrict__ xT,
-                                                    double* __restrict__ Gw, int64_t S,
-                                                    double* __restrict__ qoi, int* __restrict__ info) {
+                                                    const int* __restrict__ fD, const int* __restrict__ fM,
+                                                    const double* __restrict__ rhs, const double* __restrict__ fImm,
+                                                    const double* __restrict__ xT, double* __restrict__ Gw, int64_t S,
+                                                    int* __restrict__ info) {
   // LDS: [cache_slots] row cache | NEG1 | ZERO | INV | XREG | BAD | x[xdim] (fused assembly only), each 64 lanes x 8 B.  The interpreter state that
   // only the rare ops touch (1/L_ii of the current row, the LDX operand, the failure flag) lives in LDS, not in
   // registers: loop-carried registers that the common multiply-add does not modify cost a register move per
@@ -219,42 +216,75 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
     }
 #undef VM_STEP
   }
+  // A sample whose matrix turned out not to be positive definite: NaN right-hand side, so that the substitution kernel
+  // produces NaN w and NaN QoI for it (rows outside the failed pivot's subtree would otherwise look fine), and the flag.
   const int bad = rc[S_BAD * 64] != 0.0;
-
-  // ---- backward: L^T w = y, w overwrites y ----------------------------------------------
-  if (p.debug_phases & 2) {
-    const int* __restrict__ A = bA; const int* __restrict__ KB = bKB; const int* __restrict__ D = bD;
-    // short stream (one op per entry of L): fetched chunk by chunk without double buffering, which keeps
-    // the kernel under 96 VGPRs so that two of its waves and two projection waves share a SIMD
-    double a1[VM_CHUNK], b1[VM_CHUNK];
-    for (int c = 0; c < p.nchunks_bwd; ++c) {
-      int kbv[VM_CHUNK], dv[VM_CHUNK];
-#pragma unroll
-      for (int u = 0; u < VM_CHUNK; ++u) { kbv[u] = KB[c * VM_CHUNK + u]; dv[u] = D[c * VM_CHUNK + u]; }
-#pragma unroll
-      for (int u = 0; u < VM_CHUNK; ++u) {
-        const int a_ = A[c * VM_CHUNK + u];
-        const int b_ = (kbv[u] >> 8) - 1;
-        a1[u] = ldg(a_ < 0 ? 0 : a_);
-        b1[u] = ldg(b_ < 0 ? 0 : b_);
-      }
-#pragma unroll
-      for (int u = 0; u < VM_CHUNK; ++u) {
-        const int kind = kbv[u] & 255;
-        if (kind == B_WFMA) acc = fma(-a1[u], b1[u], acc);
-        else if (kind == B_WSET) acc = a1[u];
-        else if (kind == B_WFIN) G[(int64_t)dv[u] * 64] = acc * a1[u];
-      }
-    }
-  }
-#undef VM_LOAD1
-
-  // ---- QoI = B_obs w  (fom :408-412), loads batched by 8 -------------------------------
   const int64_t s = blk * 64 + lane;
-  const double nanv = __builtin_nan("");
+  if (bad) {
+    const double nanv = __builtin_nan("");
+    for (int i = 0; i < p.n; ++i) G[(int64_t)(p.nnzL + p.n + i) * 64] = nanv;
+  }
+  if (info != nullptr && s < S && bad) atomicOr(&info[s], 1);   // the ROM half may set bit 1 concurrently
+  trace_end(p.trace, blk);
+}
+
+// ---- backward: L^T w = y (w overwrites y), then QoI = B_obs w (fom :408-412) -------------------------------------------
+// Its own kernel: no LDS, hence not tied to the forward interpreter's LDS-limited residency or its register budget, and the
+// operands of chunk c+1 are in flight while chunk c executes (a value stored in chunk c is not fetched before chunk c+2,
+// as in the forward stream).  Ops: WSET acc = G[a] | WFMA acc -= G[a] * G[b] | WFIN G[d] = acc * G[a].
+__global__ __launch_bounds__(64) void fom_bwd_kernel(FomDev p, const int* __restrict__ A, const int* __restrict__ B,
+                                                     const int* __restrict__ KD, const int* __restrict__ obs_ptr,
+                                                     const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                     double* __restrict__ Gw, int64_t S, double* __restrict__ qoi) {
+  const unsigned lane = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;
+  double* G = Gs + lane;
+  const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000);
+  const int lane8 = (int)lane * 8;
+  auto ldgb = [&](int byte_off) -> double {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(gres, lane8, byte_off, 0));
+  };
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  auto stg = [&](double v, int e) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), gres, lane8, e * 512, 0);
+  };
+  double acc = 0.0;
+  if (p.debug_phases & 2) {
+    // The operands of chunk c+1 are in flight while chunk c executes; the descriptors of a step -- kinds of chunk c, operand
+    // offsets of chunk c+1 -- are requested a whole step before they are used.  (Two chunks ahead measured slower, 3.29 vs
+    // 3.04 ms per 100k samples: this kernel moves 196 KB per sample at 6.4 TB/s, it is bandwidth-bound.)
+    double a0[VM_CHUNK], b0[VM_CHUNK], a1[VM_CHUNK], b1[VM_CHUNK];
+#define BW_DESC(kd, an, bn, c)                                                \
+    _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                    \
+      kd[u] = KD[(c) * VM_CHUNK + u]; an[u] = A[((c) + 1) * VM_CHUNK + u]; bn[u] = B[((c) + 1) * VM_CHUNK + u]; \
+    }
+#define BW_STEP(ca, cb, na, nb, kd, an, bn, kdn, ann, bnn, c)                  \
+  {                                                                           \
+    _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) { na[u] = ldgb(an[u]); nb[u] = ldgb(bn[u]); } \
+    BW_DESC(kdn, ann, bnn, (c) + 1)                                           \
+    _Pragma("unroll") for (int u = 0; u < VM_CHUNK; ++u) {                    \
+      const int kind = kd[u] & 255;                                           \
+      if (kind == B_WFMA) acc = fma(-ca[u], cb[u], acc);                      \
+      else if (kind == B_WSET) acc = ca[u];                                   \
+      else if (kind == B_WFIN) stg(acc * ca[u], kd[u] >> 8);                  \
+    }                                                                         \
+  }
+#pragma unroll
+    for (int u = 0; u < VM_CHUNK; ++u) { a0[u] = ldgb(A[u]); b0[u] = ldgb(B[u]); }
+    int kdA[VM_CHUNK], anA[VM_CHUNK], bnA[VM_CHUNK], kdB[VM_CHUNK], anB[VM_CHUNK], bnB[VM_CHUNK];
+    BW_DESC(kdA, anA, bnA, 0)
+    for (int c = 0; c < p.nchunks_bwd; c += 2) {     // (two spare chunks of padding cover the look-ahead and an odd count)
+      BW_STEP(a0, b0, a1, b1, kdA, anA, bnA, kdB, anB, bnB, c)
+      BW_STEP(a1, b1, a0, b0, kdB, anB, bnB, kdA, anA, bnA, c + 1)
+    }
+#undef BW_DESC
+#undef BW_STEP
+  }
+  const int64_t s = blk * 64 + lane;
   const double* wv = G + (int64_t)(p.nnzL + p.n) * 64;
   if (p.debug_phases & 4)
-  for (int o = 0; o < p.n_obs; ++o) {
+  for (int o = 0; o < p.n_obs; ++o) {      // loads batched by 8
     double q0 = 0.0, q1 = 0.0;
     const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
     for (int t = t0; t < t1; t += 8) {
@@ -267,12 +297,8 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
         q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
       }
     }
-    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : (q0 + q1);
+    if (s < S) qoi[s * p.n_obs + o] = q0 + q1;       // NaN for a flagged sample: its w is NaN
   }
-  if (bad)
-    for (int i = 0; i < p.n; ++i) G[(int64_t)(p.nnzL + p.n + i) * 64] = nanv;
-  if (info != nullptr && s < S && bad) atomicOr(&info[s], 1);   // the ROM half may set bit 1 concurrently
-  trace_end(p.trace, blk);
 }
 
 int launch_fom_assemble(const FomDev& p, const double* xT, int64_t nblk, double* Gw, hipStream_t st) {
@@ -289,11 +315,13 @@ int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, doubl
   ScopedKernelTimer t(K_FOM, st);
   const size_t lds = (size_t)(p.cache_slots + 5 + (p.fused ? p.xdim : 0)) * 64 * sizeof(double);
   if (p.fwd_chunk == 16)
-    hipLaunchKernelGGL(fom_vm_kernel<16>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.b_a, p.b_kb,
-                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, p.f_imm, xT, Gw, S, qoi, info);
+    hipLaunchKernelGGL(fom_vm_kernel<16>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.rhs, p.f_imm, xT,
+                       Gw, S, info);
   else
-    hipLaunchKernelGGL(fom_vm_kernel<8>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.b_a, p.b_kb,
-                       p.b_d, p.rhs, p.obs_ptr, p.obs_idx, p.obs_w, p.f_imm, xT, Gw, S, qoi, info);
+    hipLaunchKernelGGL(fom_vm_kernel<8>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.rhs, p.f_imm, xT,
+                       Gw, S, info);
+  FR_HIP(hipGetLastError());
+  hipLaunchKernelGGL(fom_bwd_kernel, dim3((unsigned)nblk), dim3(64), 0, st, p, p.b_a, p.b_b, p.b_kd, p.obs_ptr, p.obs_idx, p.obs_w, Gw, S, qoi);
   FR_HIP(hipGetLastError());
   return 0;
 }

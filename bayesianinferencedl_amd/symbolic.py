@@ -335,7 +335,7 @@ class CholeskyPlan:
 # The factorisation / substitution schedule is flattened into a stream of fixed-size ops that a
 # wave executes for its 64 samples.  The wave fetches the ops' global operands one CHUNK (8 ops)
 # ahead of executing them, so a value stored while chunk c executes may be fetched no earlier than
-# for chunk c+2 (forward stream; the short backward stream is fetched chunk by chunk: c+1).  This module orders the rows (any topological order of the elimination tree is a
+# for chunk c+2 (both streams).  This module orders the rows (any topological order of the elimination tree is a
 # valid elimination order) and pads with NOPs so that rule always holds; tests/test_host_and_abi.py
 # replays the stream with exactly that prefetch semantics.
 #
@@ -536,7 +536,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
 
     # ---------------- backward: L^T w = y (w overwrites y) --------------------------------
     col_ptr = plan.col_ptr.astype(np.int64)
-    emb = _Emitter(nnzL + 2 * n, distance=1)     # the backward interpreter fetches chunk c right before executing it
+    emb = _Emitter(nnzL + 2 * n, distance=2)     # the substitution kernel fetches one chunk ahead, like the forward interpreter
     ndeps_b = np.diff(col_ptr)
     users_b = [[] for _ in range(n)]
     for i in range(n):
@@ -562,7 +562,7 @@ def build_op_streams(plan: "CholeskyPlan", cache_slots: int, rhs_nonzero=None, f
             heapq.heappush(eligible, (nh, i))
         if eligible:
             _, i = heapq.heappop(eligible)
-            ready = max([done_b[plan.col_row[c]] + 1 for c in range(col_ptr[i], col_ptr[i + 1])], default=0)
+            ready = max([done_b[plan.col_row[c]] + 2 for c in range(col_ptr[i], col_ptr[i + 1])], default=0)
             if ready > cur and (eligible or (waiting and waiting[0][0] < ready)):
                 heapq.heappush(waiting, (ready, -depth[i], i))
                 continue
@@ -654,12 +654,11 @@ def replay_op_streams(plan, streams, A_entries, rhs_perm, cache_slots, x=None):
             va = G[np.maximum(a[sl], 0)].copy()
             vb = G[np.maximum(b[sl], 0)].copy() if backward else None
             return va, vb
-        nxt = fetch(0)
+        ahead = 1                                   # both streams: chunk c+1 is fetched BEFORE chunk c executes
+        queue = [fetch(j) for j in range(ahead)]
         for c in range(nch):
-            if backward:
-                cur = fetch(c)                      # backward: chunk c is fetched right before it executes
-            else:
-                cur, nxt = nxt, fetch(c + 1)        # forward: chunk c+1 is fetched BEFORE chunk c executes
+            queue.append(fetch(c + ahead))
+            cur = queue.pop(0)
             for u in range(CH):
                 t = c * CH + u
                 k, ld = kind[t], cur[0][u]

@@ -88,7 +88,7 @@ int finrom_profile_read(int slot, const char** name, int64_t* launches, double* 
  * and executes two op streams (factorisation + L y = F, then L^T w = y).  A wave (64 samples,
  * lane = sample) fetches the global operands of chunk c+1 (fwd_chunk = 8 or 16 ops) before it executes chunk c,
  * so the host must order/pad the forward stream such that a value stored in chunk c is not loaded
- * before chunk c+2 (the backward stream is fetched chunk by chunk: not before c+1); checked at create.  Ops (kind, a, b, d), acc = per-sample accumulator,
+ * before chunk c+2 (both streams; the backward stream runs in its own kernel, 8 ops per chunk); checked at create.  Ops (kind, a, b, d), acc = per-sample accumulator,
  * rc = the LDS row cache (cache_slots entries; holds the row being eliminated and whatever the host left in the other slots):
  *   forward  0 FMA acc -= rc[b]*G[a]   (rc[cache_slots] == -1 and rc[cache_slots+1] == 0 are constants:
  *                  "acc = A_e" is an FMA against the first, padding an FMA against the second with a = -1)
