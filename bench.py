@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--projection", default="direct", choices=["direct", "offline_online"],
                     help="how the timed region forms A_r: 'direct' = per-sample psi^T psi on MFMA (what the reference executes, the "
                          "headline); 'offline_online' = precomputed Gram blocks (same results, ~50x fewer ROM flops)")
+    ap.add_argument("--no-other", action="store_true", help="skip the extra (untimed) pass with the other --projection")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-host-io", action="store_true", help="skip the extra (untimed) host-buffer pass")
     return ap.parse_args()
@@ -218,7 +219,7 @@ def main():
 
     # context only, after the timed region: the same steps with the OTHER form of the reduced operator (see --projection)
     other = None
-    if not args.no_profile:
+    if not args.no_profile and not args.no_other:
         other_mode = "offline_online" if args.projection == "direct" else "direct"
         solver_r.set_projection(other_mode)
         step(); fence()

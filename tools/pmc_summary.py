@@ -26,17 +26,19 @@ summary = {"workload_key": key,
                    "FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled "
                    "as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE exact).",
            "raw": raw, "hbm_bytes_per_launch": {}, "l2_hit_rate": {}, "mfma_busy_frac": {}}
-slot_of = {"fom_vm_kernel": "fom_chol_solve", "fom_assemble_kernel": "fom_assemble", "rom_proj_kernel": "rom_proj_mfma",
+slot_of = {"fom_vm_kernel": "fom_chol_solve", "fom_bwd_kernel": "fom_chol_solve", "rom_gram_kernel": "rom_proj_mfma", "rom_gram_store_kernel": "rom_proj_mfma", "fom_assemble_kernel": "fom_assemble", "rom_proj_kernel": "rom_proj_mfma",
            "rom_proj_lds_kernel": "rom_proj_mfma", "rom_proj_kernel_r80": "rom_proj_mfma", "rom_proj_single_kernel": "rom_proj_mfma", "rom_solve_kernel": "rom_reduced_solve", "subfin_avg_kernel": "subfin_avg",
            "pack_kernel": "pack"}
 for k, c in raw.items():
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-        summary["hbm_bytes_per_launch"][slot_of.get(k, k)] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:      # kernels that share a timer slot (FOM forward + backward) add up
+        summary["hbm_bytes_per_launch"][slot_of.get(k, k)] = summary["hbm_bytes_per_launch"].get(slot_of.get(k, k), 0) + \
+            int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+        summary.setdefault("hbm_bytes_per_kernel", {})[k] = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
     if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
-        summary["l2_hit_rate"][slot_of.get(k, k)] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        summary["l2_hit_rate"][k] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
     if c.get("GRBM_GUI_ACTIVE", 0) > 0 and c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0:
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
-        summary["mfma_busy_frac"][slot_of.get(k, k)] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 4)
+        summary["mfma_busy_frac"][k] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 4)
 with open(os.path.join(out, "pmc_summary.json"), "w") as fh:
     json.dump(summary, fh, indent=1)
 print(json.dumps({k: summary[k] for k in ("hbm_bytes_per_launch", "l2_hit_rate", "mfma_busy_frac")}, indent=1))
