@@ -297,6 +297,21 @@ def test_create_rejects_corrupt_descriptors(spaces):
         d.fwd_chunk = 12
         seen["bad_chunk"] = real(C.byref(d), C.byref(h))
         d.fwd_chunk = old_chunk
+        # a both-operands-in-LDS multiply-add (kind 11) whose slot no FINOFF has written yet, and one beyond the cache
+        kinds = np.ctypeslib.as_array(d.fwd_kind, shape=(d.nops_fwd,))
+        t11 = int(np.nonzero(kinds == 11)[0][0]) if (kinds == 11).any() else None
+        seen["has_fmall"] = t11 is not None
+        if t11 is not None:
+            old = d.fwd_d[t11]
+            d.fwd_d[t11] = d.cache_slots                      # beyond the row cache
+            seen["bad_slot"] = real(C.byref(d), C.byref(h))
+            d.fwd_d[t11] = old
+            first_off = int(np.nonzero(kinds == 5)[0][0])     # before the first FINOFF nothing is in the cache
+            ok, oa, ob, od = d.fwd_kind[0], d.fwd_a[0], d.fwd_b[0], d.fwd_d[0]
+            assert first_off > 0
+            d.fwd_kind[0], d.fwd_a[0], d.fwd_b[0], d.fwd_d[0] = 11, -1, 0, 0
+            seen["unwritten_slot"] = real(C.byref(d), C.byref(h))
+            d.fwd_kind[0], d.fwd_a[0], d.fwd_b[0], d.fwd_d[0] = ok, oa, ob, od
         old = d.perm[0]
         d.perm[0] = d.perm[1]                                 # not a permutation
         seen["bad_perm"] = real(C.byref(d), C.byref(h))
@@ -309,6 +324,7 @@ def test_create_rejects_corrupt_descriptors(spaces):
         lib.finrom_fom_create = real
     assert seen["bad_index"][0] != 0 and b"invalid" in seen["bad_index"][1]
     assert seen["bad_chunk"] != 0 and seen["bad_perm"] != 0
+    assert seen["has_fmall"] and seen["bad_slot"] != 0 and seen["unwritten_slot"] != 0
     assert (np.asarray(res["info"]) == 0).all()
 
 
