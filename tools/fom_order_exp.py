@@ -19,9 +19,10 @@ def main():
     m = int(os.environ.get("EXP_M", "12"))
     X = torch.from_numpy(np.random.default_rng(3).uniform(0.1, 10.0, (S, 5))).cuda()
     engines = []
+    exp_env = set()
     for spec in specs:
         for k in list(os.environ):
-            if k.startswith("FINROM_") and k.endswith("_ORDER"):
+            if k.startswith("FINROM_") and (k.endswith("_ORDER") or k in exp_env):
                 del os.environ[k]
         import bayesianinferencedl_amd.engine as E
         E.ROW_CACHE_SLOTS = 40
@@ -29,7 +30,9 @@ def main():
         for kv in spec.split(","):
             if kv:
                 k, v = kv.split("=")
-                if k == "CHUNK":
+                if k.startswith("ENV_"):             # ENV_NAME=v -> FINROM_NAME=v for this engine's creation
+                    os.environ["FINROM_" + k[4:]] = v; exp_env.add("FINROM_" + k[4:])
+                elif k == "CHUNK":
                     E.FWD_CHUNK = int(v)
                 elif k == "CACHE":
                     E.ROW_CACHE_SLOTS = int(v)          # LDS slots incl. the x slots of the fused assembly
