@@ -92,6 +92,13 @@ __device__ __forceinline__ void mfma_drain(d4 (&acc)[N]) {
 // shuffles inside the block row; the update of the trailing tiles is 4 MFMAs per tile whose operands ARE
 // the freshly computed registers of U (A[i][k] = U[k][i] lives exactly where the C/D layout put it).
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double read_lane_f64(double v, int lane) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 template <int NB>
 __device__ __forceinline__ int tile_index(int ti, int tj) { return ti * NB - (ti * (ti - 1)) / 2 + (tj - ti); }
 
@@ -110,7 +117,7 @@ __device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, i
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
       const int qs = st & 3, gs = st >> 2;
-      const double piv = __shfl(acc[dg][gs], qs * 16 + st);
+      const double piv = read_lane_f64(acc[dg][gs], qs * 16 + st);      // wave-uniform source lane: v_readlane, no LDS round trip
       bad |= !(piv > 0.0);
       double rinv = __builtin_amdgcn_rsq(piv);                 // 1/sqrt: hardware estimate + Newton steps
 #pragma unroll
@@ -167,12 +174,6 @@ __device__ __forceinline__ int chol_tiles(d4 (&acc)[NB * (NB + 1) / 2], int q, i
 // already known is reduced over the 16 lanes of its row group by xor shuffles.  Block row ti and register g are
 // unrolled, the row group qk of the step is a run-time loop (20 code copies at r = 80 instead of 80).
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double read_lane_f64(double v, int lane) {
-  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 
 template <int NB>
 __device__ __forceinline__ void solve_tiles(const d4 (&acc)[NB * (NB + 1) / 2], const double (&b)[NB],
