@@ -196,8 +196,12 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
         acc += fImm[d];                                                       \
       } else if (kind == F_FINDIAG) {                                         \
         if (!(acc > 0.0)) rc[S_BAD * 64] = 1.0;                               \
-        const double t = sqrt(acc);                                           \
-        const double inv = 1.0 / t;                                           \
+        /* 1/sqrt by the hardware estimate + two Newton steps (as in the ROM's in-register Cholesky): a tenth of the */ \
+        /* code of sqrt() and 1.0 / t, and this block exists once per op slot of the unrolled loop */ \
+        double inv = __builtin_amdgcn_rsq(acc);                               \
+        inv = inv * fma(-0.5 * acc * inv, inv, 1.5);                          \
+        inv = inv * fma(-0.5 * acc * inv, inv, 1.5);                          \
+        const double t = acc * inv;                                           \
         stg(t, d);                                                            \
         stg(inv, p.nnzL + b);                                                 \
         rc[S_INV * 64] = inv;                                                 \
