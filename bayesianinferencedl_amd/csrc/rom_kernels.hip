@@ -14,6 +14,7 @@
 // upper block triangle of A_r (NB(NB+1)/2 tiles of 16x16).  Bound: fp64 MFMA issue.
 #include "finrom_internal.h"
 
+#include <cstdlib>
 #include "rom_proj_device.h"
 
 namespace finrom {
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
     double out = 0.0;
 #pragma unroll
     for (int u = 0; u < NSET; ++u)
-      if ((pr >> 6) == u) out = __shfl(x[u], pr & 63);
+      if ((pr >> 6) == u) out = read_lane_f64(x[u], pr & 63);      // wave-uniform source lane: v_readlane, no LDS round trip
     return out;
   };
 
@@ -589,11 +590,12 @@ int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_
                      double* Ar_out, double* Br_out, int* info, int factored, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  const size_t lds = ((p.solve_in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 2 * (size_t)p.rp) * sizeof(double);
+  const bool in_lds = p.solve_in_lds;
+  const size_t lds = ((in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 2 * (size_t)p.rp) * sizeof(double);
   const int nset = (p.rp + 63) / 64;
 #define FR_SOLVE(L, N, F) return launch_solve_t<L, N, F>(p, lds, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info, st)
   if (factored) {
-    if (!p.solve_in_lds) FR_SOLVE(false, 4, true);
+    if (!in_lds) FR_SOLVE(false, 4, true);
     if (nset == 1) FR_SOLVE(true, 1, true);
     if (nset == 2) FR_SOLVE(true, 2, true);
     FR_SOLVE(true, 3, true);
