@@ -260,20 +260,26 @@ def test_edge_batch_sizes(problems, spaces, S):
         assert np.linalg.norm(np.asarray(res["qoi_r"])[i] - qr) < TOL * np.linalg.norm(qr)
 
 
-def test_fwd_chunk_16_stream_gives_the_same_solution(problems, spaces, monkeypatch):
-    """The interpreter is instantiated for 8- and 16-op prefetch chunks (finrom_fom_desc.fwd_chunk)."""
+@pytest.mark.parametrize("chunk,cache,m,params", [(16, 5, 4, "nine"), (8, 17, 12, "five"), (8, 13, 12, "nine")])
+def test_fwd_chunk_16_stream_gives_the_same_solution(problems, spaces, monkeypatch, chunk, cache, m, params):
+    """The interpreter is instantiated for 8- and 16-op prefetch chunks (finrom_fom_desc.fwd_chunk); small row caches
+    exercise the LDX / FMAX ops (rows longer than the cache) and the wrap-around of the ring allocation, with the affine
+    assembly fused into the stream (17 slots, five parameters) and as a pre-pass (5 and 13 slots, nine parameters)."""
     import bayesianinferencedl_amd.engine as E
     from bayesianinferencedl_amd.fom.forward_solve import Fin
     from bayesianinferencedl_amd.fom.thermal_fin import get_space
-    m = 4
     prob = problems(m)
     fo = O.FinOracle(prob)
     rng = np.random.default_rng(4)
-    X = rng.uniform(0.1, 10.0, (70, 9))
-    monkeypatch.setattr(E, "FWD_CHUNK", 16)
-    monkeypatch.setattr(E, "ROW_CACHE_SLOTS", 5)          # also exercises the LDX / FMAX ops
-    res = Fin(get_space(40, m=m)).forward_batch(X, want_w=True, params="nine")
-    W = np.array([fo.forward(fo.nine_param_to_function(X[i])) for i in range(8)])
+    X = rng.uniform(0.1, 10.0, (70, 9 if params == "nine" else 5))
+    monkeypatch.setattr(E, "FWD_CHUNK", chunk)
+    monkeypatch.setattr(E, "ROW_CACHE_SLOTS", cache)
+    fin = Fin(get_space(40, m=m))
+    res = fin.forward_batch(X, want_w=True, params=params)
+    eng = fin._engine(params)
+    assert eng.fused == (cache == 17) and eng.cache_slots == (12 if cache == 17 else cache)
+    lift = fo.nine_param_to_function if params == "nine" else fo.five_param_to_function
+    W = np.array([fo.forward(lift(X[i])) for i in range(8)])
     assert rel(np.asarray(res["w"])[:8], W) < TOL
 
 
