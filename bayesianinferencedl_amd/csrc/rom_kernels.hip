@@ -547,6 +547,119 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Blocked substitutions for wide bases (96 < r <= 208) with the factor left in global memory: wave = sample, lane l owns
+// rows l, l + 64, ...  Columns go in blocks of 16: the 16 x 16 diagonal tile is solved in registers (16 dependent steps,
+// pivots passed by v_readlane), everything else is a throughput phase -- forward, the rows below the block subtract
+// L[i][block] . y_block (16 independent, lane-coalesced column loads per row set); backward, the rows above the block
+// subtract L[block][i] . x_block (column i is contiguous: one 128-byte segment per lane).  8 - 13 sequential block steps instead
+// of 2 r pivot steps with an LDS round trip each, no LDS (so as many waves per CU as registers allow), the factor read twice.
+// ---------------------------------------------------------------------------------------
+template <int NSET>
+__global__ __launch_bounds__(64) void rom_subst_blocked_kernel(RomDev p, const double* __restrict__ Lp, const double* __restrict__ Br,
+                                                               int64_t S, double* __restrict__ w_r, double* __restrict__ qoi_r) {
+  const int r = p.r, R = p.rp, np = R * (R + 1) / 2;
+  const int lane = threadIdx.x;
+  const int64_t s = blockIdx.x;
+  const double* __restrict__ L = Lp + s * (int64_t)np;
+  __shared__ double xs[256];
+  int row[NSET];
+  double b[NSET];
+#pragma unroll
+  for (int u = 0; u < NSET; ++u) {
+    row[u] = lane + 64 * u;
+    b[u] = row[u] < R ? Br[s * R + row[u]] : 0.0;
+  }
+  auto bcast = [&](const double (&x)[NSET], int pr) -> double {      // value of row pr (wave-uniform)
+    double out = 0.0;
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+      if ((pr >> 6) == u) out = read_lane_f64(x[u], pr & 63);
+    return out;
+  };
+  // ---- forward: L y = b ----------------------------------------------------------------
+  for (int jb = 0; jb < R; jb += 16) {
+    const int u0 = jb >> 6, l0 = jb & 63, li = lane - l0;      // lanes l0 .. l0 + 15 of row set u0 own the block's rows
+    const bool mine = li >= 0 && li < 16;
+    double t[16];                                               // row li of the diagonal tile: L[jb + li][jb + j], j <= li
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t[j] = (mine && j <= li) ? L[col_start(jb + j, R) + li - j] : 0.0;
+    double y[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double bj = 0.0;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) if (u == u0) bj = b[u];
+      const double yj = read_lane_f64(bj, l0 + j) / read_lane_f64(t[j], l0 + j);
+      y[j] = yj;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u)
+        if (u == u0) b[u] = (mine && li == j) ? yj : ((mine && li > j) ? fma(-t[j], yj, b[u]) : b[u]);
+    }
+    // rows below the block
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      const int i = row[u];
+      if (i >= jb + 16 && i < R) {
+        double lv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lv[j] = L[col_start(jb + j, R) + i - (jb + j)];
+        double acc = b[u];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fma(-lv[j], y[j], acc);
+        b[u] = acc;
+      }
+    }
+  }
+  // ---- backward: L^T x = y ---------------------------------------------------------------
+  for (int jb = R - 16; jb >= 0; jb -= 16) {
+    const int u0 = jb >> 6, l0 = jb & 63, li = lane - l0;
+    const bool mine = li >= 0 && li < 16;
+    double t[16];                                               // column li of the tile: L[jb + j][jb + li], j >= li (contiguous)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t[j] = (mine && j >= li) ? L[col_start(jb + li, R) + j - li] : 0.0;
+    double x[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 15 - jj;
+      double bj = 0.0;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) if (u == u0) bj = b[u];
+      const double xj = read_lane_f64(bj, l0 + j) / read_lane_f64(t[j], l0 + j);     // lane l0 + j holds L[jb+j][jb+j] in t[j]
+      x[j] = xj;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u)
+        if (u == u0) b[u] = (mine && li == j) ? xj : ((mine && li < j) ? fma(-t[j], xj, b[u]) : b[u]);
+    }
+    // rows above the block: L[jb + j][i], j = 0..15, are 16 consecutive entries of column i
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      const int i = row[u];
+      if (i < jb) {
+        const double* __restrict__ src = L + col_start(i, R) + jb - i;
+        double lv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) lv[j] = src[j];
+        double acc = b[u];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = fma(-lv[j], x[j], acc);
+        b[u] = acc;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NSET; ++u) {
+    if (row[u] < R) xs[row[u]] = b[u];
+    if (w_r != nullptr && row[u] < r) w_r[s * r + row[u]] = b[u];
+  }
+  __syncthreads();
+  for (int o = lane; o < p.n_obs; o += 64) {
+    double qv = 0.0;
+    for (int tt = 0; tt < r; ++tt) qv = fma(p.obs_phi[o * r + tt], xs[tt], qv);
+    qoi_r[s * p.n_obs + o] = qv;
+  }
+}
+
 template <bool IN_LDS, int NSET, bool FACTORED>
 static int launch_solve_t(const RomDev& p, size_t lds, const double* Ar, const double* Br, int64_t S, double* w_r,
                           double* qoi_r, double* Ar_out, double* Br_out, int* info, hipStream_t st) {
@@ -594,6 +707,16 @@ int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_
   const size_t lds = ((in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 2 * (size_t)p.rp) * sizeof(double);
   const int nset = (p.rp + 63) / 64;
 #define FR_SOLVE(L, N, F) return launch_solve_t<L, N, F>(p, lds, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info, st)
+  static const bool old_subst = getenv("FINROM_OLD_SUBST") != nullptr;
+  if (factored && p.NB > 6 && Ar_out == nullptr && Br_out == nullptr && !old_subst) {      // wide bases: blocked substitutions
+    switch (nset) {
+      case 2: hipLaunchKernelGGL(rom_subst_blocked_kernel<2>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
+      case 3: hipLaunchKernelGGL(rom_subst_blocked_kernel<3>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
+      default: hipLaunchKernelGGL(rom_subst_blocked_kernel<4>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
+    }
+    FR_HIP(hipGetLastError());
+    return 0;
+  }
   if (factored) {
     if (!in_lds) FR_SOLVE(false, 4, true);
     if (nset == 1) FR_SOLVE(true, 1, true);
