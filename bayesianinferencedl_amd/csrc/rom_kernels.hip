@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void rom_chol_blocked_kernel(RomDev p, double* 
 #pragma unroll
           for (int g = 0; g < 4; ++g) dtile[g] = rowt[tj][g];
         }
-      const double piv = __shfl(dtile[gs], qs * 16 + st);
+      const double piv = read_lane_f64(dtile[gs], qs * 16 + st);      // wave-uniform source lane
       bad |= !(piv > 0.0);
       double rinv = __builtin_amdgcn_rsq(piv);
 #pragma unroll
