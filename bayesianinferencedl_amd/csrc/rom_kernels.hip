@@ -27,7 +27,7 @@ namespace finrom {
 // written back as rows of U (= columns of L in the packed layout the substitution kernel reads).
 // ---------------------------------------------------------------------------------------
 template <int NB>
-__global__ __launch_bounds__(64) void rom_chol_blocked_kernel(RomDev p, double* __restrict__ Arp, int64_t S,
+__global__ __launch_bounds__(64, NB <= 8 ? 3 : 2) void rom_chol_blocked_kernel(RomDev p, double* __restrict__ Arp, int64_t S,
                                                               int* __restrict__ info) {
   const int lane = threadIdx.x, q = lane >> 4, c = lane & 15;
   const int64_t s = blockIdx.x;
