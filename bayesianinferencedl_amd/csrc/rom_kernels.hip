@@ -548,7 +548,8 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
 }
 
 // ---------------------------------------------------------------------------------------
-// Blocked substitutions for wide bases (96 < r <= 208) with the factor left in global memory: wave = sample, lane l owns
+// Blocked substitutions for bases wider than 80 (the factor comes from the projection kernel's in-register Cholesky for
+// r <= 96, from the blocked Cholesky kernel beyond) with the factor left in global memory: wave = sample, lane l owns
 // rows l, l + 64, ...  Columns go in blocks of 16: the 16 x 16 diagonal tile is solved in registers (16 dependent steps,
 // pivots passed by v_readlane), everything else is a throughput phase -- forward, the rows below the block subtract
 // L[i][block] . y_block (16 independent, lane-coalesced column loads per row set); backward, the rows above the block
@@ -708,7 +709,7 @@ int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_
   const int nset = (p.rp + 63) / 64;
 #define FR_SOLVE(L, N, F) return launch_solve_t<L, N, F>(p, lds, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info, st)
   static const bool old_subst = getenv("FINROM_OLD_SUBST") != nullptr;
-  if (factored && p.NB > 6 && Ar_out == nullptr && Br_out == nullptr && !old_subst) {      // wide bases: blocked substitutions
+  if (factored && p.NB >= 6 && Ar_out == nullptr && Br_out == nullptr && !old_subst) {     // r > 80: blocked substitutions
     switch (nset) {
       case 2: hipLaunchKernelGGL(rom_subst_blocked_kernel<2>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
       case 3: hipLaunchKernelGGL(rom_subst_blocked_kernel<3>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
