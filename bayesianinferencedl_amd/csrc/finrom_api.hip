@@ -84,7 +84,7 @@ struct finrom_fom_s {
 struct finrom_rom_s {
   RomDev d{};
   std::vector<void*> owned;
-  Scratch Ar, Br, theta, qtmp;
+  Scratch Ar, Br, theta, qtmp, vw;
   int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
   RomGramDev gram;                     // offline/online form (finrom_rom_set_gram); gram.h is filled at create
   int projection = FINROM_PROJECTION_DIRECT;
@@ -665,7 +665,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
 void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release();
+  h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release();
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -806,8 +806,16 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
     ga.data = data + (data_per_sample ? s0 * d.n_obs : 0); ga.data_stride = data_per_sample ? d.n_obs : 0;
     ga.theta = theta + s0 * d.P; ga.J = J + s0; ga.g = g + s0 * d.P;
     ga.npairs = h->g_npairs; ga.pair_p = h->g_pair_p; ga.pair_i = h->g_pair_i; ga.Gt = h->g_Gt;
+    // batches: the contraction with the blocks G_pi runs on the matrix cores for 16 samples at a time; a handful of samples
+    // (the one-sample call pattern) keep it inside the substitution kernel (one launch less)
+    const bool batched = Sc >= 64 && d.n_obs <= 64 && getenv("FINROM_OLD_SUBST") == nullptr && getenv("FINROM_GRAD_INLINE") == nullptr;
+    if (batched) {
+      if ((rc = h->vw.reserve((size_t)Sc * 2 * d.rp * sizeof(double)))) return rc;
+      ga.vw = (double*)h->vw.p;
+    }
     if ((rc = launch_rom_grad(d, (const double*)h->Ar.p, (const double*)h->Br.p, Sc, w_r ? w_r + s0 * d.r : nullptr, q,
                               info ? info + s0 : nullptr, ga, st))) return rc;
+    if (batched && (rc = launch_rom_grad_contract(d, Sc, ga, st))) return rc;
   }
   return 0;
 }

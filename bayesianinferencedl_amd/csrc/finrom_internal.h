@@ -156,6 +156,8 @@ struct RomGradArgs {                      // adjoint-gradient stage of rom_solve
   const double* theta = nullptr;                            // [S x P]
   double* J = nullptr; double* g = nullptr;                 // [S], [S x P]
   int npairs = 0; const int* pair_p = nullptr; const int* pair_i = nullptr; const double* Gt = nullptr;
+  double* vw = nullptr;     // scratch [S x 2 rp]: when set, the substitution kernel leaves v_r and w_r there and the
+                            // contraction g_i = sum_p theta_p v_r^T G_pi w_r runs in rom_grad_contract_kernel (fp64 MFMA, 16 samples per wave)
 };
 // offline/online form of the reduced operator (finrom_rom_set_gram, rom_gram.hip)
 constexpr int ROM_GRAM_MAX_PAIRS = 64;
@@ -170,6 +172,7 @@ int launch_rom_gram(const RomDev& p, const RomGramDev& gm, const double* theta, 
                     int* info, hipStream_t st, double* w_r = nullptr, double* qoi_r = nullptr);
 int launch_rom_grad(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
                     int* info, const RomGradArgs& ga, hipStream_t st);
+int launch_rom_grad_contract(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st);
 int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, hipStream_t st);
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st,
                     double* w_r = nullptr, double* qoi_r = nullptr);

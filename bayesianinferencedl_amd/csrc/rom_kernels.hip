@@ -556,28 +556,9 @@ __global__ __launch_bounds__(64) void rom_solve_kernel(RomDev p, const double* _
 // subtract L[block][i] . x_block (column i is contiguous: one 128-byte segment per lane).  8 - 13 sequential block steps instead
 // of 2 r pivot steps with an LDS round trip each, no LDS (so as many waves per CU as registers allow), the factor read twice.
 // ---------------------------------------------------------------------------------------
+// b <- (L L^T)^{-1} b for the rows this lane owns (row[u] = lane + 64 u)
 template <int NSET>
-__global__ __launch_bounds__(64) void rom_subst_blocked_kernel(RomDev p, const double* __restrict__ Lp, const double* __restrict__ Br,
-                                                               int64_t S, double* __restrict__ w_r, double* __restrict__ qoi_r) {
-  const int r = p.r, R = p.rp, np = R * (R + 1) / 2;
-  const int lane = threadIdx.x;
-  const int64_t s = blockIdx.x;
-  const double* __restrict__ L = Lp + s * (int64_t)np;
-  __shared__ double xs[256];
-  int row[NSET];
-  double b[NSET];
-#pragma unroll
-  for (int u = 0; u < NSET; ++u) {
-    row[u] = lane + 64 * u;
-    b[u] = row[u] < R ? Br[s * R + row[u]] : 0.0;
-  }
-  auto bcast = [&](const double (&x)[NSET], int pr) -> double {      // value of row pr (wave-uniform)
-    double out = 0.0;
-#pragma unroll
-    for (int u = 0; u < NSET; ++u)
-      if ((pr >> 6) == u) out = read_lane_f64(x[u], pr & 63);
-    return out;
-  };
+__device__ __forceinline__ void subst_blocked(const double* __restrict__ L, const int (&row)[NSET], double (&b)[NSET], int R, int lane) {
   // ---- forward: L y = b ----------------------------------------------------------------
   for (int jb = 0; jb < R; jb += 16) {
     const int u0 = jb >> 6, l0 = jb & 63, li = lane - l0;      // lanes l0 .. l0 + 15 of row set u0 own the block's rows
@@ -648,17 +629,148 @@ __global__ __launch_bounds__(64) void rom_subst_blocked_kernel(RomDev p, const d
       }
     }
   }
+}
+
+template <int NSET, bool GRAD>
+__global__ __launch_bounds__(64) void rom_subst_blocked_kernel(RomDev p, const double* __restrict__ Lp, const double* __restrict__ Br,
+                                                               int64_t S, double* __restrict__ w_r, double* __restrict__ qoi_r,
+                                                               RomGradArgs ga) {
+  const int r = p.r, R = p.rp, np = R * (R + 1) / 2;
+  const int lane = threadIdx.x;
+  const int64_t s = blockIdx.x;
+  const double* __restrict__ L = Lp + s * (int64_t)np;
+  __shared__ double xs[256];
+  __shared__ double rs[64];
+  int row[NSET];
+  double b[NSET];
+#pragma unroll
+  for (int u = 0; u < NSET; ++u) {
+    row[u] = lane + 64 * u;
+    b[u] = row[u] < R ? Br[s * R + row[u]] : 0.0;
+  }
+  subst_blocked<NSET>(L, row, b, R, lane);
 #pragma unroll
   for (int u = 0; u < NSET; ++u) {
     if (row[u] < R) xs[row[u]] = b[u];
     if (w_r != nullptr && row[u] < r) w_r[s * r + row[u]] = b[u];
   }
   __syncthreads();
+  double jl = 0.0;
   for (int o = lane; o < p.n_obs; o += 64) {
     double qv = 0.0;
     for (int tt = 0; tt < r; ++tt) qv = fma(p.obs_phi[o * r + tt], xs[tt], qv);
-    qoi_r[s * p.n_obs + o] = qv;
+    if (qoi_r != nullptr) qoi_r[s * p.n_obs + o] = qv;
+    if constexpr (GRAD) {
+      const double res = ga.data[(ga.data_stride ? s * ga.data_stride : 0) + o] - qv;
+      rs[o] = res;
+      jl = fma(res, res, jl);
+    }
   }
+  if constexpr (GRAD) {
+    // adjoint gradient, the same steps as the GRAD stage of rom_solve_kernel (rom/averaged_affine_ROM.py:335-356):
+    //   v_r = A_r^{-T} (B_obs Phi)^T (data - obs),  g_i = sum_p theta_p v_r^T G_pi w_r
+    for (int off = 32; off > 0; off >>= 1) jl += __shfl_xor(jl, off);
+    __syncthreads();
+    double v[NSET];
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+      double acc = 0.0;
+      if (row[u] < r)
+        for (int o = 0; o < p.n_obs; ++o) acc = fma(p.obs_phi[o * r + row[u]], rs[o], acc);
+      v[u] = acc;
+    }
+    subst_blocked<NSET>(L, row, v, R, lane);
+    if (lane == 0) ga.J[s] = 0.5 * jl;
+    if (ga.vw != nullptr) {                        // the contraction runs batched on the matrix cores (rom_grad_contract_kernel)
+      double* dst = ga.vw + s * (int64_t)(2 * R);
+#pragma unroll
+      for (int u = 0; u < NSET; ++u)
+        if (row[u] < R) { dst[row[u]] = row[u] < r ? v[u] : 0.0; dst[R + row[u]] = row[u] < r ? xs[row[u]] : 0.0; }
+      return;
+    }
+    double g = 0.0;                                // lane i accumulates g_i
+    for (int pi = 0; pi < ga.npairs; ++pi) {
+      const double* Gt = ga.Gt + (int64_t)pi * r * r;     // stored column by column: Gt[c * r + row]
+      double part = 0.0;
+#pragma unroll
+      for (int u = 0; u < NSET; ++u) {
+        if (row[u] < r) {
+          double t2 = 0.0;
+          for (int c2 = 0; c2 < r; ++c2) t2 = fma(Gt[c2 * r + row[u]], xs[c2], t2);
+          part = fma(v[u], t2, part);
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      const int pp = ga.pair_p[pi];
+      const double thp = pp == 0 ? 1.0 : ga.theta[s * p.P + pp - 1];
+      if (lane == ga.pair_i[pi]) g = fma(thp, part, g);
+    }
+    if (lane < p.P) ga.g[s * p.P + lane] = g;
+  }
+}
+
+// g[s][i] = sum over the listed pairs (p, i) of theta_p[s] * v_s^T G_pi w_s for 16 samples per wave: T = V G_pi on the fp64
+// matrix cores (A = V tile [16 samples x 4], B = G [4 x 16 columns]), then the row sums of T o W.  One wave reads every block
+// G_pi once per 16 samples (per sample in the substitution kernel's own loop: 1.7 MB each at r = 80, the L2 -> L1 traffic that
+// bounded it).  V and W tiles sit in LDS.
+__global__ __launch_bounds__(64) void rom_grad_contract_kernel(RomDev p, int64_t S, RomGradArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) double cs[];
+  const int r = p.r, R = p.rp;
+  const int lane = threadIdx.x, q = lane >> 4, c = lane & 15;
+  const int64_t s0 = (int64_t)blockIdx.x * 16;
+  double* Vs = cs;                   // [16][R]
+  double* Ws = cs + 16 * R;          // [16][R]
+  double* gs = cs + 32 * R;          // [16][32]
+  for (int t = lane; t < 16 * R; t += 64) {
+    const int sl = t / R, col = t - sl * R;
+    const bool ok = s0 + sl < S;
+    Vs[t] = ok ? ga.vw[(s0 + sl) * (int64_t)(2 * R) + col] : 0.0;
+    Ws[t] = ok ? ga.vw[(s0 + sl) * (int64_t)(2 * R) + R + col] : 0.0;
+  }
+  for (int t = lane; t < 16 * 32; t += 64) gs[t] = 0.0;
+  __syncthreads();
+  const int nct = (r + 15) / 16;
+  for (int pi = 0; pi < ga.npairs; ++pi) {
+    const double* __restrict__ G = ga.Gt + (int64_t)pi * r * r;      // G[k][j] = G[j * r + k]
+    double part[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int ct = 0; ct < nct; ++ct) {
+      const int col = 16 * ct + c;
+      d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int k0 = 0; k0 < r; k0 += 4) {
+        const int k = k0 + q;
+        const double a = k < r ? Vs[c * R + k] : 0.0;                  // A[i = c][k = q]: sample c of the tile
+        const double b = (k < r && col < r) ? G[(int64_t)col * r + k] : 0.0;   // B[k = q][j = c]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) part[g] = fma(acc[g], Ws[(q + 4 * g) * R + col], part[g]);   // D[row = q + 4g][col = c]; W is 0 beyond r
+    }
+    const int pp = ga.pair_p[pi], ii = ga.pair_i[pi];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double x = part[g];
+      x += __shfl_xor(x, 8); x += __shfl_xor(x, 4); x += __shfl_xor(x, 2); x += __shfl_xor(x, 1);
+      const int sl = q + 4 * g;
+      if (c == 0 && s0 + sl < S) {
+        const double thp = pp == 0 ? 1.0 : ga.theta[(s0 + sl) * p.P + pp - 1];
+        gs[sl * 32 + ii] = fma(thp, x, gs[sl * 32 + ii]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = lane; t < 16 * p.P; t += 64) {
+    const int sl = t / p.P, i = t - sl * p.P;
+    if (s0 + sl < S) ga.g[(s0 + sl) * p.P + i] = gs[sl * 32 + i];
+  }
+}
+
+int launch_rom_grad_contract(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_ROM_SOLVE, st);
+  const size_t lds = ((size_t)32 * p.rp + 16 * 32) * sizeof(double);
+  hipLaunchKernelGGL(rom_grad_contract_kernel, dim3((unsigned)((S + 15) / 16)), dim3(64), lds, st, p, S, ga);
+  FR_HIP(hipGetLastError());
+  return 0;
 }
 
 template <bool IN_LDS, int NSET, bool FACTORED>
@@ -692,8 +804,20 @@ int launch_rom_grad(const RomDev& p, const double* Ar, const double* Br, int64_t
                     int* info, const RomGradArgs& ga, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  const size_t lds = ((p.solve_in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 3 * (size_t)p.rp + 64) * sizeof(double);
   const int nset = (p.rp + 63) / 64;
+  static const bool old_subst = getenv("FINROM_OLD_SUBST") != nullptr;
+  if (!old_subst && p.n_obs <= 64) {      // blocked substitutions with the factor in global memory, both solves + the gradient
+    const dim3 grid((unsigned)S), block(64);
+    switch (nset) {
+      case 1: hipLaunchKernelGGL((rom_subst_blocked_kernel<1, true>), grid, block, 0, st, p, Ar, Br, S, w_r, qoi_r, ga); break;
+      case 2: hipLaunchKernelGGL((rom_subst_blocked_kernel<2, true>), grid, block, 0, st, p, Ar, Br, S, w_r, qoi_r, ga); break;
+      case 3: hipLaunchKernelGGL((rom_subst_blocked_kernel<3, true>), grid, block, 0, st, p, Ar, Br, S, w_r, qoi_r, ga); break;
+      default: hipLaunchKernelGGL((rom_subst_blocked_kernel<4, true>), grid, block, 0, st, p, Ar, Br, S, w_r, qoi_r, ga); break;
+    }
+    FR_HIP(hipGetLastError());
+    return 0;
+  }
+  const size_t lds = ((p.solve_in_lds ? (size_t)p.rp * (p.rp + 1) / 2 : 0) + 3 * (size_t)p.rp + 64) * sizeof(double);
   if (!p.solve_in_lds) return launch_grad_t<false, 4>(p, lds, Ar, Br, S, w_r, qoi_r, info, ga, st);   // r > 176: factor in global memory
   if (nset == 1) return launch_grad_t<true, 1>(p, lds, Ar, Br, S, w_r, qoi_r, info, ga, st);
   if (nset == 2) return launch_grad_t<true, 2>(p, lds, Ar, Br, S, w_r, qoi_r, info, ga, st);
@@ -711,9 +835,9 @@ int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_
   static const bool old_subst = getenv("FINROM_OLD_SUBST") != nullptr;
   if (factored && p.NB >= 6 && Ar_out == nullptr && Br_out == nullptr && !old_subst) {     // r > 80: blocked substitutions
     switch (nset) {
-      case 2: hipLaunchKernelGGL(rom_subst_blocked_kernel<2>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
-      case 3: hipLaunchKernelGGL(rom_subst_blocked_kernel<3>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
-      default: hipLaunchKernelGGL(rom_subst_blocked_kernel<4>, dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r); break;
+      case 2: hipLaunchKernelGGL((rom_subst_blocked_kernel<2, false>), dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r, RomGradArgs()); break;
+      case 3: hipLaunchKernelGGL((rom_subst_blocked_kernel<3, false>), dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r, RomGradArgs()); break;
+      default: hipLaunchKernelGGL((rom_subst_blocked_kernel<4, false>), dim3((unsigned)S), dim3(64), 0, st, p, Ar, Br, S, w_r, qoi_r, RomGradArgs()); break;
     }
     FR_HIP(hipGetLastError());
     return 0;
