@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   // FINROM_FOM_PHASES bits 4 / 5 (timing experiments only, results are garbage): FINOFF does not store to global memory /
   // every op takes the multiply-add path
   const int xmask = (p.debug_phases & 32) ? 0 : -1;
+  const int nogroup = (p.debug_phases & 128) ? 0xFFFF : 0;      // bit 7: no group-of-four path (A/B)
   const bool nostore = p.debug_phases & 16;
 
 #define VM_LOAD1(buf, c)                                                      \
@@ -170,7 +171,17 @@ __global__ __launch_bounds__(64, 5) void fom_vm_kernel(FomDev p, const int* __re
   }                                                                           \
   const int msk = fM[c];                                                      \
   _Pragma("unroll") for (int u = 0; u < FCH; ++u) nxt[u] = ldgb(an[u]);       \
-  _Pragma("unroll") for (int u = 0; u < FCH; ++u) {                           \
+  _Pragma("unroll") for (int h4 = 0; h4 < FCH; h4 += 4)                       \
+  if ((((msk & xmask) | nogroup) & (0xF << h4)) == 0) {                       \
+    /* four plain multiply-adds in a row (42 % of the groups): one test, the eight LDS operands requested together */ \
+    double l1[4], l2[4];                                                      \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                           \
+      l1[u] = *reinterpret_cast<const double*>(rcb + kbv[h4 + u]);            \
+      l2[u] = *reinterpret_cast<const double*>(rcb + dv[h4 + u]);             \
+    }                                                                         \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) acc = fma(-l1[u], buf[h4 + u] + l2[u], acc); \
+  } else                                                                      \
+  _Pragma("unroll") for (int u = h4; u < h4 + 4; ++u) {                       \
     const double ld = buf[u];                                                 \
     if (__builtin_expect(!(msk & xmask & (1 << u)), 1)) {                     \
       /* acc -= rc[b] * (G[a] + rc[d]): one of the two is exactly zero (FMA: d = the ZERO slot; FMALL: a out of range); */ \
