@@ -240,7 +240,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
   std::vector<int> fkb(a->nops_fwd), bkb(a->nops_bwd);
   // device encoding of the forward stream: load offsets in bytes, the common multiply-adds (FMA, FMALL) carry the LDS
   // byte offsets of their row-cache slots in kb and d, every other op kind | (b+1) << 8, and one bit mask per chunk flags
-  // the slots that are NOT plain multiply-adds
+  // the slots that are NOT plain multiply-adds (bits 0..15) and the multiply-adds whose second operand is in LDS (bits 16..31)
   std::vector<int> fa2(a->nops_fwd), fd2(a->nops_fwd), fmask(a->nops_fwd / a->fwd_chunk, 0);
   const bool noload = getenv("FINROM_FOM_NOLOAD") != nullptr;      // timing experiment: no operand fetches (results are garbage)
   for (int t = 0; t < a->nops_fwd; ++t) {
@@ -251,7 +251,8 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
     // the common multiply-add is acc -= rc[b] * (G[a] + rc[d']): FMA reads the ZERO slot as d', FMALL an out-of-range G[a]
     // the common multiply-add is acc -= rc[b] * (G[a] + rc[d']): FMA reads the ZERO slot as d', FMALL an out-of-range G[a]
     if (a->fwd_kind[t] == 0) { fkb[t] = a->fwd_b[t] * 512; fd2[t] = (a->cache_slots + 1) * 512; }
-    else if (a->fwd_kind[t] == 11) { fkb[t] = a->fwd_b[t] * 512; fd2[t] = a->fwd_d[t] * 512; }
+    else if (a->fwd_kind[t] == 11) { fkb[t] = a->fwd_b[t] * 512; fd2[t] = a->fwd_d[t] * 512;
+                                       fmask[t / a->fwd_chunk] |= 1 << (16 + t % a->fwd_chunk); }     // second operand in LDS
     else { fkb[t] = a->fwd_kind[t] | ((a->fwd_b[t] + 1) << 8); fmask[t / a->fwd_chunk] |= 1 << (t % a->fwd_chunk); }
   }
   // backward stream on the device: byte offsets of both operands (out of range = no operand: the fetch returns 0 without
