@@ -1,0 +1,94 @@
+"""Minimal Hamiltonian Monte Carlo driver for BASELINE configs[4]: chains of sequential, DEPENDENT one-sample
+value-and-gradient calls of the ROM + learned-error misfit (`AffineROMFin.grad_romml`), the call pattern PyMC3's NUTS
+drives through the reference's Theano op (bayesian_inference/pymc_func_bayes_inverse.py:92-104 `err_grad_ROMML`,
+:148-167 `SqErrorOpROMML.perform`, model :186-203: potential = misfit / sigma^2 on a latent Gaussian field).
+
+PyMC3 / Theano are control plane and out of scope; what the hot path needs from them is the leapfrog recursion
+that makes every evaluation's input depend on the previous evaluation's gradient.  This module is that recursion and
+nothing more: fixed-length leapfrog trajectories with a Metropolis test, an i.i.d. Gaussian prior around a mean field (the
+reference's Matern-5/2 latent GP would add a dense n x n triangular solve per step on the HOST, which is not the path
+measured here), independent chains seeded `seed + chain`.
+
+Chains are independent, so C chains may advance in LOCKSTEP: one device call evaluates the current leapfrog point of every
+chain (a batch of C samples), each chain keeping its own momentum, random stream and accept/reject decision.  On N GPUs a
+rank owns chains `rank, rank + N, ...` (one chain per GPU at N = C) and there is no communication until the traces are
+gathered."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class HmcResult(dict):
+    __getattr__ = dict.__getitem__
+
+
+def potential(loss, grad, K, mean, sigma, tau):
+    """U(k) = loss(k) / sigma^2 + |k - mean|^2 / (2 tau^2) and its gradient, row-wise for a batch K [C, n]."""
+    d = K - mean
+    U = np.asarray(loss, dtype=np.float64) / sigma ** 2 + 0.5 * np.einsum("cn,cn->c", d, d) / tau ** 2
+    return U, np.asarray(grad, dtype=np.float64) / sigma ** 2 + d / tau ** 2
+
+
+def run_chains(value_and_grad, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, sigma=0.05, tau=0.5, mean=None, record=None,
+               keep_trace=False):
+    """Advance C = len(K0) chains in lockstep for `n_evals` value-and-gradient evaluations per chain.
+
+    value_and_grad(K [C, n]) -> (loss [C], grad [C, n], bad [C] bool): ONE device call per leapfrog point; `bad` marks
+    samples whose reduced operator was not positive definite (treated as infinite potential: the proposal is rejected).
+    record: optional set of evaluation indices whose (input, loss, gradient) are kept for parity checks.
+    Returns HmcResult(K [C, n] final states, accept [C] accepted proposals, proposals, n_evals (per chain),
+    trace [proposals + 1, C, n] if keep_trace, recorded = list of (eval index, K copy, loss, grad) for parity checks)."""
+    K = np.array(K0, dtype=np.float64, copy=True)
+    C, n = K.shape
+    mean = K.copy() if mean is None else np.broadcast_to(np.asarray(mean, dtype=np.float64), K.shape)
+    rngs = [np.random.default_rng(s) for s in seeds]
+    assert len(rngs) == C
+    recorded = []
+    evals = 0
+
+    def evaluate(Kq):
+        nonlocal evals
+        loss, grad, bad = value_and_grad(Kq)
+        if record is not None and evals in record:
+            recorded.append((evals, Kq.copy(), np.array(loss, copy=True), np.array(grad, copy=True)))
+        evals += 1
+        U, dU = potential(loss, grad, Kq, mean, sigma, tau)
+        bad = np.asarray(bad, dtype=bool) | ~np.isfinite(U)
+        U = np.where(bad, np.inf, U)
+        dU = np.where(bad[:, None], 0.0, dU)
+        return U, dU
+
+    U, dU = evaluate(K)                                              # evaluation 0: the starting point
+    if not np.all(np.isfinite(U)):
+        raise ValueError("HMC start point has an indefinite reduced operator")
+    trace = [K.copy()] if keep_trace else None
+    accept = np.zeros(C, np.int64)
+    proposals = 0
+    while evals + n_leapfrog <= n_evals:
+        P = np.stack([r.standard_normal(n) for r in rngs])
+        H0 = U + 0.5 * np.einsum("cn,cn->c", P, P)
+        Kq, Pq, Uq, dUq = K.copy(), P.copy(), U, dU
+        for _ in range(n_leapfrog):                                  # each step's input depends on the previous gradient
+            Pq = Pq - 0.5 * eps * dUq
+            Kq = Kq + eps * Pq
+            Uq, dUq = evaluate(Kq)
+            Pq = Pq - 0.5 * eps * dUq
+        H1 = Uq + 0.5 * np.einsum("cn,cn->c", Pq, Pq)
+        u = np.array([r.uniform() for r in rngs])
+        with np.errstate(over="ignore", invalid="ignore"):
+            ok = np.isfinite(H1) & (np.log(u) < H0 - H1)
+        K = np.where(ok[:, None], Kq, K); U = np.where(ok, Uq, U); dU = np.where(ok[:, None], dUq, dU)
+        accept += ok
+        proposals += 1
+        if keep_trace:
+            trace.append(K.copy())
+    return HmcResult(K=K, accept=accept, proposals=proposals, n_evals=evals, recorded=recorded,
+                     trace=np.stack(trace) if keep_trace else None)
+
+
+def romml_value_and_grad(solver_r):
+    """The evaluation the reference's SqErrorOpROMML performs, batched over chains: AffineROMFin.grad_romml_batch."""
+    def f(K):
+        res = solver_r.grad_romml_batch(K)
+        return np.asarray(res["loss"]), np.asarray(res["grad"]), np.asarray(res["info"]) != 0
+    return f

@@ -46,7 +46,55 @@ def parse():
     ap.add_argument("--no-other", action="store_true", help="skip the extra (untimed) pass with the other --projection")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-host-io", action="store_true", help="skip the extra (untimed) host-buffer pass")
+    ap.add_argument("--workload", default="pairs", choices=["pairs", "hmc"],
+                    help="pairs: the FOM+ROM dataset loop (BASELINE metric, configs[1..3]); hmc: BASELINE configs[4], chains of "
+                         "sequential dependent one-sample ROM + learned-error value-and-gradient calls (steps = calls per chain)")
+    ap.add_argument("--chains", type=int, default=4, help="hmc: number of independent chains (sharded over the GPUs)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 run: nccl (= RCCL over xGMI, one rank per GPU) or gloo (host "
+                         "gather; ranks may then share a GPU: rehearsal of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / sharding rehearsal without a GPU: ranks start, build their shard of the globally keyed "
+                         "inputs, gather a stand-in over gloo and rank 0 prints the JSON line with value = null")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: THIS process only launches.  It starts N fresh rank
+    processes (torch.distributed.run, rendezvous on 127.0.0.1) BEFORE anything here has touched the GPU -- no torch import,
+    no library load, no exec of an initialised process -- and relays rank 0's JSON line (the children inherit stdout)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def global_uniform(seed, lo, hi, dim, a=0.1, b=10.0, block=4096):
+    """Rows [lo, hi) of the ONE global input stream: block j of `block` rows comes from default_rng([seed, j]), so a rank's
+    shard is the same numbers whatever the GPU count and nobody materialises the other ranks' rows."""
+    out = np.empty((hi - lo, dim))
+    for j in range(lo // block, (hi + block - 1) // block if hi > lo else lo // block):
+        rows = np.random.default_rng([seed, j]).uniform(a, b, (block, dim))
+        g0, g1 = max(lo, j * block), min(hi, (j + 1) * block)
+        out[g0 - lo:g1 - lo] = rows[g0 - j * block:g1 - j * block]
+    return out
+
+
+def global_normal(seed, lo, hi, dim, block=1024):
+    """As global_uniform, standard normals (the xi of the Gaussian-field sampler when drawn on the host)."""
+    out = np.empty((hi - lo, dim))
+    for j in range(lo // block, (hi + block - 1) // block if hi > lo else lo // block):
+        rows = np.random.default_rng([seed, j]).standard_normal((block, dim))
+        g0, g1 = max(lo, j * block), min(hi, (j + 1) * block)
+        out[g0 - lo:g1 - lo] = rows[g0 - j * block:g1 - j * block]
+    return out
 
 
 def flops_per_pair(ops, plan, rom, n_obs, P):
@@ -115,9 +163,20 @@ def cpu_baseline_all_cores(args):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            launch_ranks(args)                             # never returns
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if args.workload == "hmc":
+        return run_hmc(args, rank, local_rank, world)
     cpu_all = None
     if world == 1 and args.cpu_samples > 0 and args.params != "field":
         try:
@@ -128,11 +187,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible); RCCL needs one GPU per rank "
+                         "(--backend gloo lets ranks share a GPU for a rehearsal)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from bayesianinferencedl_amd import _ffi
     from bayesianinferencedl_amd.fom.thermal_fin import get_space
@@ -140,7 +207,7 @@ def main():
     from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
     from bayesianinferencedl_amd.rom.basis import pod_basis
     from bayesianinferencedl_amd.pairs import FinPairSolver
-    _ffi.check(_ffi.lib().finrom_set_device(local_rank))
+    _ffi.check(_ffi.lib().finrom_set_device(dev_index))
 
     V = get_space(None, m=args.m)
     solver = Fin(V)
@@ -152,24 +219,25 @@ def main():
     S = args.samples
     # inputs are keyed by the GLOBAL sample index, so rank g's shard is rows [g*S, (g+1)*S) of
     # the same stream whatever the GPU count (results independent of G)
-    rng = np.random.default_rng(3)
     if args.params == "field":
         from bayesianinferencedl_amd.bayesian_inference.gaussian_field import make_cov_chol
         from bayesianinferencedl_amd.engine import FieldSampler
-        rng = np.random.default_rng(3 + rank)
-        xi = torch.from_numpy(rng.standard_normal((S, V.dim()))).to(dev)
-        X = FieldSampler(make_cov_chol(V, length=1.6))(xi)
+        sampler = FieldSampler(make_cov_chol(V, length=1.6))
+        X = torch.empty((S, V.dim()), dtype=torch.float64, device=dev)
+        for s0 in range(0, S, 16384):                      # xi in pieces: bounded host memory at the 125k-sample shard
+            s1 = min(S, s0 + 16384)
+            xi = torch.from_numpy(global_normal(5, rank * S + s0, rank * S + s1, V.dim())).to(dev)
+            X[s0:s1] = sampler(xi)
         del xi
     else:
-        Xg = rng.uniform(0.1, 10.0, (world * S, pairs.xdim))
-        X = torch.from_numpy(Xg[rank * S:(rank + 1) * S]).to(dev)
-        del Xg
+        X = torch.from_numpy(global_uniform(3, rank * S, (rank + 1) * S, pairs.xdim)).to(dev)
     from bayesianinferencedl_amd.distributed import gather_rows
 
     def step():
         res = pairs.solve_pairs(X)
         if world > 1:   # the one exchange step: QoI pairs of every shard (RCCL all_gather over xGMI)
-            res["gathered"] = gather_rows(torch.cat([res["qoi"], res["qoi_r"]], dim=1), world)
+            loc = torch.cat([res["qoi"], res["qoi_r"]], dim=1)
+            res["gathered"] = gather_rows(loc if args.backend == "nccl" else loc.cpu(), world)
         return res
 
     def fence():
@@ -212,10 +280,16 @@ def main():
     prof = _ffi.profile_read()
     n_bad = int((res["info"] != 0).sum().item())
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")        # where the collectives' tensors live
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # checksum of the gathered QoI pairs in GLOBAL sample order (not timed): equal for every GPU count on the same total
+    import hashlib
+    full = res["gathered"] if world > 1 else torch.cat([res["qoi"], res["qoi_r"]], dim=1)
+    gathered_sha = hashlib.sha256(full.cpu().numpy().tobytes()).hexdigest() if rank == 0 else None
+    del full
 
     # context only, after the timed region: the same steps with the OTHER form of the reduced operator (see --projection)
     other = None
@@ -230,7 +304,7 @@ def main():
         fence()
         dto = time.perf_counter() - t0
         L.finrom_profile_enable(0)
-        tmax = torch.tensor([dto], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dto], dtype=torch.float64, device=cdev)
         if world > 1:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dto = float(tmax.item())
@@ -300,12 +374,184 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0},
+            "gathered_sha256": gathered_sha, "backend": args.backend if world > 1 else None,
             "kernels_serial_ms": serial_ms,
             "host_io_pairs_per_s": host_io,
             "cpu_baseline_all_cores": cpu_all,
             "other_projection": other,
         }
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_hmc(args, rank, local_rank, world):
+    """BASELINE configs[4]: `--chains` independent HMC chains (seed 6 + chain), each a sequence of `--steps` DEPENDENT
+    one-sample evaluations of AffineROMFin.grad_romml (ROM adjoint + error-model value and input gradient; reference
+    bayesian_inference/pymc_func_bayes_inverse.py:92-104,148-167, rom/averaged_affine_ROM.py:358-396) at m = 12, r = 81.
+    Rank g owns chains g, g + N, ...; the chains of one rank advance in lockstep (one device call evaluates the current
+    leapfrog point of each).  A step = one value-and-gradient evaluation of every chain; value = evaluations / s."""
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible)")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible)")
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+    from bayesianinferencedl_amd import _ffi
+    from bayesianinferencedl_amd.fom.thermal_fin import get_space
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    from bayesianinferencedl_amd.rom.basis import pod_basis
+    from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel
+    from bayesianinferencedl_amd.bayesian_inference import hmc
+    _ffi.check(_ffi.lib().finrom_set_device(dev_index))
+    r = 81 if args.r == 80 else args.r                      # configs[4] is quoted at r = 81 (SURVEY 8(d) cfg 5)
+    V = get_space(None, m=args.m)
+    solver = Fin(V)
+    phi = pod_basis(solver, r, n_snapshots=400, low=0.1, high=10.0, params="nine", seed=1)
+    model = hmc_error_model(V.dim())
+    solver_r = AffineROMFin(V, model, phi, projection=args.projection)
+    k_true = np.exp(0.25 * global_normal(11, 0, 1, V.dim())[0])
+    solver_r.set_data(solver.qoi_operator(solver.forward(k_true)[0]))
+    mine = [c for c in range(args.chains) if c % world == rank]
+    K0 = np.stack([np.exp(0.1 * np.random.default_rng(6 + c).standard_normal(V.dim())) for c in mine]) if mine else np.zeros((0, V.dim()))
+    f = hmc.romml_value_and_grad(solver_r)
+    L = 10
+    n_evals = 1 + args.steps // L * L                       # evaluation 0 (the start point) + whole trajectories
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(n):
+        return hmc.run_chains(f, K0, n, seeds=[6 + c for c in mine], n_leapfrog=L) if mine else None
+    run(1 + max(L, args.warmup // L * L))
+    fence()
+    Lb = _ffi.lib()
+    Lb.finrom_profile_reset(); Lb.finrom_profile_enable(0 if args.no_profile else 1)
+    t0 = time.perf_counter()
+    res = run(n_evals)
+    fence()
+    dt = time.perf_counter() - t0
+    Lb.finrom_profile_enable(0)
+    prof = _ffi.profile_read()
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    # one chain alone, one sample per call: the per-call latency a single PyMC chain would see (not timed above)
+    lat = None
+    if rank == 0 and mine:
+        n1 = 1 + min(200, args.steps) // L * L
+        hmc.run_chains(f, K0[:1], 1 + L, seeds=[6], n_leapfrog=L)
+        t1 = time.perf_counter()
+        hmc.run_chains(f, K0[:1], n1, seeds=[6], n_leapfrog=L)
+        lat = (time.perf_counter() - t1) / n1
+    if rank == 0:
+        total = args.chains * n_evals
+        ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in prof.items()}
+        dom = max(prof, key=lambda k: prof[k][1]) if any(v[1] for v in prof.values()) else None
+        roof = None
+        if dom == "rom_proj_mfma" and ms[dom] > 0 and args.projection == "direct":
+            ops = V.operators()
+            alg = len(mine) * (ops.n * r * (r + 1) + 2 * solver_r._rom.nterms * r + r ** 3 // 3)
+            ach = alg / (ms[dom] * 1e-3) / 1e12
+            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms[dom],
+                    "note": "latency-bound workload: one wave per chain runs the whole contraction; the fraction is what one call leaves of the chip, not a kernel-quality figure"}
+        cpu = None
+        if world == 1 and args.cpu_samples > 0:
+            cpu = hmc_cpu_baseline(args, phi, model, solver_r.data, K0, res)
+        print(json.dumps({
+            "metric": "ROM+DL value-and-gradient evaluations/sec (HMC chains, BASELINE configs[4])",
+            "value": total / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / n_evals, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64 (ROM) + f32 (error model)", "data": "synthetic",
+            "config": {"workload": f"HMC: {args.chains} chains x {n_evals} dependent one-sample grad_romml calls, lattice m={args.m} "
+                                   f"(n={V.dim()}), r={r}, res_bn_fc error model 5 x 50, {L} leapfrog steps per proposal, "
+                                   f"{len(mine)} chains per call on rank 0", "chains": args.chains, "evals_per_chain": n_evals,
+                       "r": r, "projection": args.projection, "accepted": res["accept"].tolist() if res else None,
+                       "proposals": res["proposals"] if res else None},
+            "roofline": roof, "cpu_baseline": cpu, "single_chain_latency_ms_per_call": None if lat is None else 1e3 * lat,
+            "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def hmc_error_model(n):
+    """res_bn_fc error model of the reference's load_bn_model(randobs=False) shape (5 units x 50, deep_learning/dl_model.py:
+    225), random weights and non-trivial batch-norm statistics (no checkpoint can be read here), small output scale."""
+    from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel
+    rng = np.random.default_rng(7)
+    model = ResBnFcModel(n, 9, 5, 50, seed=7)
+    for u in model.units + [model.head]:
+        u["gamma"] = rng.uniform(0.5, 1.5, u["gamma"].shape).astype(np.float32)
+        u["beta"] = rng.normal(0, 0.2, u["beta"].shape).astype(np.float32)
+        u["mean"] = rng.normal(0, 0.2, u["mean"].shape).astype(np.float32)
+        u["var"] = rng.uniform(0.5, 2.0, u["var"].shape).astype(np.float32)
+    model.head["W"] *= np.float32(0.02)
+    return model
+
+
+def hmc_cpu_baseline(args, phi, model, data, K0, res):
+    """oracle.grad_romml_oracle (dense NumPy restatement of rom/averaged_affine_ROM.py:358-396) on one core, a bounded
+    number of evaluations at the chains' start points."""
+    from oracle import fin_oracle as O
+    try:
+        from threadpoolctl import threadpool_limits
+        lim = threadpool_limits(limits=1)
+    except Exception:
+        lim = None
+    ro = O.AffineROMOracle(O.FinProblem(args.m), phi)
+    ro.set_data(data)
+    t0 = time.perf_counter(); done = 0
+    while done < args.cpu_samples and time.perf_counter() - t0 < 20.0:
+        O.grad_romml_oracle(ro, model, K0[done % len(K0)])
+        done += 1
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "evals/s", "cores": 1, "kind": "port",
+            "sample": f"{done} evaluations of oracle.grad_romml_oracle at the chains' start points, 1 thread"}
+
+
+def dry_run(args, rank, world):
+    """No GPU: the launcher, the rank environment, the global keying of the inputs and the gather, over gloo.  Each rank
+    'solves' its shard with a stand-in (row sums); rank 0 checks the gathered array against the single-process one and
+    prints the JSON line of the contract with value = null."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    from bayesianinferencedl_amd.distributed import gather_rows
+    S, dim = args.samples, {"five": 5, "nine": 9, "field": 16}[args.params]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    gen = global_normal if args.params == "field" else global_uniform
+    X = gen(3, rank * S, (rank + 1) * S, dim)
+    local = torch.from_numpy(np.stack([X.sum(1), (X * X).sum(1)], 1))
+    t0 = time.perf_counter()
+    full = gather_rows(local, world) if world > 1 else local
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        Xall = gen(3, 0, world * S, dim)
+        ref = np.stack([Xall.sum(1), (Xall * Xall).sum(1)], 1)
+        assert np.array_equal(full.numpy(), ref), "gathered shards differ from the single-process stream"
+        print(json.dumps({"metric": "FOM+ROM forward-solve sample pairs/sec (five-param fin)", "value": None, "unit": "pairs/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": "dry run: launcher + sharding + gloo gather only", "samples_per_gpu": S},
+                          "dry_run": True, "gather_s": dt,
+                          "gathered_sha256": hashlib.sha256(full.numpy().tobytes()).hexdigest()}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

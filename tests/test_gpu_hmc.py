@@ -1,0 +1,73 @@
+"""BASELINE configs[4] on the HIP path: HMC chains of sequential, dependent one-sample ROM + learned-error value-and-gradient
+calls (reference bayesian_inference/pymc_func_bayes_inverse.py:92-104,148-167 -> rom/averaged_affine_ROM.py:358-396) at the
+survey's sizes (m = 12, r = 81).  Every recorded evaluation -- its input is the product of the chain's own earlier gradients
+-- is re-evaluated by the oracle's dense restatement."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import fin_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def setup(problems, spaces):
+    sys.path.insert(0, ROOT)
+    import bench
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    from bayesianinferencedl_amd.rom.basis import pod_basis
+    m, r = 12, 81
+    prob, V = problems(m), spaces(m)
+    solver = Fin(V)
+    phi = pod_basis(solver, r, n_snapshots=200, low=0.1, high=10.0, params="nine", seed=1)
+    model = bench.hmc_error_model(V.dim())
+    k_true = np.exp(0.25 * np.random.default_rng(11).standard_normal(V.dim()))
+    data = solver.qoi_operator(solver.forward(k_true)[0])
+    ro = O.AffineROMOracle(prob, phi); ro.set_data(data)
+    return V, phi, model, data, ro
+
+
+@pytest.mark.parametrize("projection", ["direct", "offline_online"])
+def test_hmc_chains_value_and_gradient_match_the_oracle(setup, projection):
+    from bayesianinferencedl_amd.bayesian_inference import hmc
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    V, phi, model, data, ro = setup
+    rom = AffineROMFin(V, model, phi, projection=projection); rom.set_data(data)
+    chains = [0, 1, 2, 3]
+    K0 = np.stack([np.exp(0.1 * np.random.default_rng(6 + c).standard_normal(V.dim())) for c in chains])
+    want = {0, 1, 10, 37, 80}
+    res = hmc.run_chains(hmc.romml_value_and_grad(rom), K0, 81, seeds=[6 + c for c in chains], record=want)
+    assert res.n_evals == 81 and res.proposals == 8 and len(res.recorded) == len(want)
+    assert res.accept.sum() > 0, "no proposal accepted: the chains did not move"
+    moved = np.linalg.norm(res.K - K0, axis=1)
+    assert (moved > 0).any()
+    for ev, K, loss, grad in res.recorded:
+        for c in range(len(chains)):
+            go, lo = O.grad_romml_oracle(ro, model, K[c])
+            # value: fp64 ROM + fp32 network output entering a residual of order 0.1 -> 1e-6 relative on the loss
+            assert abs(loss[c] - lo) <= 1e-6 * abs(lo), (ev, c, loss[c], lo)
+            assert np.linalg.norm(grad[c] - go) <= 1e-5 * np.linalg.norm(go), (ev, c)
+    # a chain alone walks the same path as the same chain advanced in lockstep with others (fp32 network: GEMV vs GEMM order)
+    solo = hmc.run_chains(hmc.romml_value_and_grad(rom), K0[1:2], 21, seeds=[7])
+    lock = hmc.run_chains(hmc.romml_value_and_grad(rom), K0[:2], 21, seeds=[6, 7])
+    assert np.linalg.norm(solo.K[0] - lock.K[1]) <= 1e-6 * np.linalg.norm(lock.K[1])
+
+
+def test_bench_hmc_mode_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "hmc", "--steps", "40", "--warmup", "10",
+                        "--cpu-samples", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["unit"] == "evals/s" and d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["chains"] == 4
+    assert d["config"]["evals_per_chain"] == 41 and d["config"]["r"] == 81
+    assert d["single_chain_latency_ms_per_call"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert abs(d["value"] - 4 * 41 / (d["ms_per_step"] * 41e-3)) < 1e-6 * d["value"]

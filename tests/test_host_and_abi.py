@@ -153,33 +153,44 @@ def test_shard_bounds_cover_everything():
             assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
 
 
-def test_gloo_world2_gather_is_identical_to_single_process(tmp_path):
-    """N>1 path on CPU: 2 ranks (gloo) each fill their shard from the GLOBAL sample index, gather,
-    and must reproduce the single-process array bit for bit (SURVEY 8(e) determinism)."""
-    script = tmp_path / "w.py"
-    script.write_text(f'''
-import os, sys
-sys.path.insert(0, {ROOT!r})
-import numpy as np, torch, torch.distributed as dist
-from bayesianinferencedl_amd.distributed import shard_bounds, gather_rows
-dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
-total = 1001
-X = np.random.default_rng(3).uniform(0.1, 10, (total, 5))      # keyed by global sample index
-lo, hi = shard_bounds(total, rank, world)
-local = torch.from_numpy(np.stack([X[lo:hi].sum(1), X[lo:hi].prod(1)], 1))   # stand-in per-sample result
-full = gather_rows(local, world, total)
-ref = np.stack([X.sum(1), X.prod(1)], 1)
-assert np.array_equal(full.numpy(), ref), "gathered result differs from the single-process result"
-if rank == 0: print("OK", full.shape)
-dist.destroy_process_group()
-''')
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
-                       capture_output=True, text=True, timeout=240, env=env)
+def _bench_json(argv, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "OK" in r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    import json
+    return json.loads(lines[0])
+
+
+def test_bench_gpus2_launches_two_ranks_and_matches_single_process():
+    """N > 1 on CPU through the SAME entry the driver uses: `python bench.py --gpus 2` must itself start two rank processes
+    (children of a parent that never touched a GPU), each rank builds its shard of the globally keyed input stream, the shards
+    are gathered (gloo) and must reproduce the one-process stream bit for bit (SURVEY 8(e) determinism).  --dry-run replaces
+    the HIP solve by a stand-in (no GPU here); tests/test_gpu_multirank.py runs the real solve the same way on the GPU box."""
+    two = _bench_json(["--gpus", "2", "--dry-run", "--samples", "5000"])
+    one = _bench_json(["--gpus", "1", "--dry-run", "--samples", "10000"])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["dry_run"] is True
+    assert two["gathered_sha256"] == one["gathered_sha256"]
+    nine = _bench_json(["--gpus", "2", "--dry-run", "--samples", "1000", "--params", "field"])
+    assert nine["n_gpus"] == 2
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=dict(os.environ, WORLD_SIZE="3", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stdout + r.stderr)
+
+
+def test_global_input_streams_do_not_depend_on_the_shard_cut():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    for gen, dim in ((b.global_uniform, 5), (b.global_normal, 7)):
+        full = gen(3, 0, 10000, dim)
+        for cut in (1, 4095, 4096, 4097, 9999):
+            assert np.array_equal(np.concatenate([gen(3, 0, cut, dim), gen(3, cut, 10000, dim)]), full)
+        assert gen(3, 500, 500, dim).shape == (0, dim)
 
 
 def test_reference_import_paths_resolve():
