@@ -28,6 +28,23 @@ import scipy.sparse as sp
 
 BIOT = 0.1  # fom/forward_solve.py:112
 
+
+import contextlib
+
+
+@contextlib.contextmanager
+def deterministic_blas():
+    """One BLAS thread for the one-time dense host products (B_obs Phi, Psi_p^T Psi_q, the POD SVD): a threaded GEMM / SVD
+    splits its sums differently for different thread counts, and the ranks of a multi-GPU run (OMP_NUM_THREADS=1 each) must
+    build the SAME operators as a lone process, bit for bit, for the outputs to be independent of the GPU count."""
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        yield
+        return
+    with threadpool_limits(limits=1):
+        yield
+
 # sub-fin bands, reference numbering (rom/averaged_affine_ROM.py:91-99):
 #   index 0..3 = fin1..4 (left,  y_b = 0.75, 1.75, 2.75, 3.75)
 #   index 4    = fin5    (centre post)

@@ -14,13 +14,17 @@ import time
 import numpy as np
 import scipy.sparse as sp
 
-from ..fem import BIOT, Function, as_nodal
+from ..fem import BIOT, Function, as_nodal, deterministic_blas
 from ..engine import FomEngine, RomEngine, SubfinAverager
 from ..fom.forward_solve import _plan_for, external_observation_matrix
 
 
 class AffineROMFin:
     def __init__(self, V, err_model, phi, external_obs=False, projection=None):
+        with deterministic_blas():
+            self._init(V, err_model, phi, external_obs, projection)
+
+    def _init(self, V, err_model, phi, external_obs, projection):
         self.fwd_time = 0.0
         self.rom_grad_time = 0.0
         self.romml_grad_time = 0.0
@@ -74,7 +78,8 @@ class AffineROMFin:
             pairs, G = [], []
             for p in range(10):
                 for q in range(p, 10):
-                    M = self._psi_tables[p].T @ self._psi_tables[q]
+                    with deterministic_blas():
+                        M = self._psi_tables[p].T @ self._psi_tables[q]
                     if p == q or np.any(M):
                         pairs.append((p, q)); G.append(M if p == q else M + M.T)
             self._rom.set_gram_blocks(pairs, np.stack(G))
@@ -135,7 +140,8 @@ class AffineROMFin:
         pairs, G = [], []
         for p in range(10):
             for i in range(9):
-                M = self._psi_tables[p].T @ self.dA_dsigmak_phi[i]
+                with deterministic_blas():
+                    M = self._psi_tables[p].T @ self.dA_dsigmak_phi[i]
                 if np.any(M):
                     pairs.append((p, i)); G.append(M)
         self._rom.set_gradient_blocks(pairs, np.stack(G))

@@ -15,7 +15,11 @@ def pod_basis(solver, r, n_snapshots=400, low=0.1, high=3.5, params="nine", seed
     dim = {"nine": 9, "five": 5}[params]
     kappa = rng.uniform(low, high, size=(n_snapshots, dim))
     Y = np.asarray(solver.forward_batch(kappa, want_w=True, params=params)["w"])   # batched device FOM
-    _, _, Vt = np.linalg.svd(Y, full_matrices=False)                              # one-time host setup
+    # one-time host setup.  One BLAS thread: a threaded SVD blocks differently for different thread counts, and ranks of a
+    # multi-GPU run (OMP_NUM_THREADS=1 each) must build the SAME basis as a lone process, bit for bit
+    from ..fem import deterministic_blas
+    with deterministic_blas():
+        _, _, Vt = np.linalg.svd(Y, full_matrices=False)
     return np.ascontiguousarray(Vt[:r].T)
 
 
