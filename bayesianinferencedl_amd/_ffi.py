@@ -46,6 +46,16 @@ class FomSmallDesc(C.Structure):
                 ("lev_ptr_f", c_i32p), ("lev_rows_f", c_i32p), ("lev_ptr_b", c_i32p), ("lev_rows_b", c_i32p)]
 
 
+class FomBandDesc(C.Structure):
+    _fields_ = [("NSF", C.c_int32), ("NSP", C.c_int32), ("NX", C.c_int32), ("nfins", C.c_int32), ("npf", C.c_int32),
+                ("nif", C.c_int32), ("npost", C.c_int32), ("nAB", C.c_int32), ("nterms", C.c_int32), ("nLx", C.c_int32),
+                ("ab_c0", c_f64p), ("ab_ptr", c_i32p), ("ab_idx", c_i32p), ("ab_w", c_f64p), ("Fg", c_f64p),
+                ("act", c_i32p), ("lx_ptr", c_i32p), ("ent_extra", c_i32p),
+                ("ecp_ptr", c_i32p), ("ecp_slot", c_i32p), ("ecp_off", c_i32p),
+                ("schur_off", c_i32p), ("iface_elim", c_i32p), ("perm", c_i32p),
+                ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p)]
+
+
 class RomDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("r", C.c_int32), ("P", C.c_int32), ("n_obs", C.c_int32),
                 ("nterms", C.c_int32),
@@ -75,6 +85,7 @@ SIGNATURES = {
     "finrom_fom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "finrom_fom_set_small": (C.c_int, [C.c_void_p, C.POINTER(FomSmallDesc)]),
     "finrom_fom_set_gradient": (C.c_int, [C.c_void_p, C.POINTER(FomGradDesc)]),
+    "finrom_fom_set_band": (C.c_int, [C.c_void_p, C.POINTER(FomBandDesc)]),
     "finrom_fom_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 5),
     "finrom_rom_create": (C.c_int, [C.POINTER(RomDesc), C.POINTER(C.c_void_p)]),
     "finrom_rom_destroy": (None, [C.c_void_p]),
@@ -114,7 +125,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 5:
+        if L.finrom_version() != 6:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -78,6 +78,8 @@ using namespace finrom;
 struct finrom_fom_s {
   FomDev d{};
   FomSmallDev small{};
+  BandDev band{};                      // frontal band sweep (finrom_fom_set_band); band.on = 0: interpreter
+  FomDev band_asm{};                   // parameters of the band sweep's assembly pre-pass (fom_assemble_kernel)
   std::vector<void*> owned;
   Scratch xT, Gw, gradT, qtmp;
 };
@@ -309,9 +311,9 @@ void finrom_fom_destroy(finrom_fom_t h) {
 
 // stages: 1 = pack + assembly, 2 = interpreter (+ unpack of w), 3 = both.  finrom_solve_pairs runs stage 1, then
 // launches the ROM half, then stage 2 (only possible when the batch fits one workspace chunk).
-static int64_t fom_chunk_samples(const FomDev& d) {
+static int64_t fom_chunk_samples(const FomDev& d, const BandDev* band = nullptr) {
   // bound the per-call workspace (L values dominate: nnzL * 8 B per sample)
-  const size_t per_sample = ((size_t)d.gsize + d.xdim) * sizeof(double);
+  const size_t per_sample = ((size_t)(band && band->on ? band->gsize : d.gsize) + d.xdim) * sizeof(double);
   const int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
   return std::max<int64_t>(64, chunk / 64 * 64);
 }
@@ -323,6 +325,27 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
     int rc;
     if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;
     return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, qoi, w, info, st);
+  }
+  if (h->band.on && getenv("FINROM_NO_BAND") == nullptr) {
+    const BandDev& b = h->band;
+    const int64_t limit = fom_chunk_samples(d, &b);
+    const int64_t npieces = (S + limit - 1) / limit;
+    const int64_t chunk = npieces <= 1 ? limit : ((S + npieces - 1) / npieces + 63) / 64 * 64;
+    for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+      const int64_t Sc = std::min(chunk, S - s0), nblk = (Sc + 63) / 64;
+      int rc;
+      if (stages & 1) {
+        if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+        if ((rc = h->Gw.reserve((size_t)nblk * b.gsize * 64 * sizeof(double)))) return rc;
+        if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
+        if ((rc = launch_fom_assemble(h->band_asm, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
+      }
+      if (stages & 2) {
+        if ((rc = launch_fom_band(b, (double*)h->Gw.p, nblk, Sc, qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
+        if (w && (rc = launch_unpack((const double*)h->Gw.p, Sc, d.n, b.gsize, b.offY, b.perm, w + s0 * d.n, st))) return rc;
+      }
+    }
+    return 0;
   }
   // equal pieces when the batch exceeds the workspace bound (a short last piece would leave the GPU mostly idle)
   const int64_t limit = fom_chunk_samples(d), npieces = (S + limit - 1) / limit;
@@ -440,6 +463,84 @@ int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* a) {
   q.small_max = a->small_max; q.nlev_f = a->nlev_f; q.nlev_b = a->nlev_b;
   q.in_lds = (size_t)(nnzL + 3 * n + d.xdim) * sizeof(double) <= (size_t)156 * 1024;      // value vector (+ adjoint region) + x
   h->small = q;
+  return 0;
+}
+
+int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
+  if (!h || !a) { set_error("fom_set_band: null argument"); return FINROM_ERR_ARG; }
+  const FomDev& d = h->d;
+  auto bad = [&](const char* what) { set_error(std::string("fom_set_band: invalid ") + what); return FINROM_ERR_ARG; };
+  if (!band_supported(a->NSF, a->NSP, a->NX)) { set_error("fom_set_band: window sizes not built into the library"); return FINROM_ERR_UNSUPPORTED; }
+  if (a->nfins < 0 || a->npf < 0 || a->nif != a->NSF - 1 || a->npost <= 0 || a->nAB <= 0 || a->nterms < 0 || a->nLx < 0) return bad("sizes");
+  const int n = d.n, G = a->nfins * (a->npf + a->nif) + a->npost;
+  if ((int64_t)a->nfins * a->npf + a->npost != n) return bad("pivot count (must equal the number of dofs)");
+  if (a->nAB < 3 * G) return bad("nAB");
+  const int64_t nL = (int64_t)a->nfins * a->npf * a->NSF + (int64_t)a->npost * a->NSP;
+  const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n;
+  if (gsize * 512 >= (int64_t)1 << 31) { set_error("fom_set_band: workspace too long for 32-bit buffer offsets"); return FINROM_ERR_UNSUPPORTED; }
+  if (a->ab_ptr[0] != 0 || a->ab_ptr[a->nAB] != a->nterms) return bad("ab_ptr");
+  for (int e = 0; e < a->nAB; ++e) if (a->ab_ptr[e + 1] < a->ab_ptr[e]) return bad("ab_ptr");
+  for (int t = 0; t < a->nterms; ++t) if (a->ab_idx[t] < 0 || a->ab_idx[t] >= d.xdim) return bad("ab_idx");
+  if (a->lx_ptr[0] != 0 || a->lx_ptr[a->npost] != a->nLx || a->ecp_ptr[0] != 0) return bad("lx_ptr / ecp_ptr");
+  for (int p = 0; p < a->npost; ++p) {
+    if (a->act[p] < 0 || a->act[p] >= (1 << a->NX)) return bad("act");
+    if (a->lx_ptr[p + 1] - a->lx_ptr[p] != __builtin_popcount((unsigned)a->act[p])) return bad("lx_ptr (must count the bits of act)");
+    if (a->ent_extra[p] < 0 || a->ent_extra[p] > a->NX) return bad("ent_extra");
+    if (a->ecp_ptr[p + 1] < a->ecp_ptr[p]) return bad("ecp_ptr");
+  }
+  for (int c = 0; c < a->ecp_ptr[a->npost]; ++c)
+    if (a->ecp_slot[c] < 0 || a->ecp_slot[c] >= a->NX || a->ecp_off[c] < 0 || a->ecp_off[c] >= a->nAB) return bad("ecp_slot / ecp_off");
+  const int nift = a->nif * (a->nif + 1) / 2;
+  for (int t = 0; t < a->nfins * nift; ++t) if (a->schur_off[t] < 0 || a->schur_off[t] >= a->nAB) return bad("schur_off");
+  for (int t = 0; t < a->nfins * a->nif; ++t) if (a->iface_elim[t] < 0 || a->iface_elim[t] >= n) return bad("iface_elim");
+  {
+    std::vector<char> seen(n, 0);
+    for (int i = 0; i < n; ++i) { int v = a->perm[i]; if (v < 0 || v >= n || seen[v]) return bad("perm"); seen[v] = 1; }
+  }
+  if (d.n_obs > 0) {
+    if (a->obs_ptr[0] != 0) return bad("obs_ptr");
+    for (int o = 0; o < d.n_obs; ++o) if (a->obs_ptr[o + 1] < a->obs_ptr[o]) return bad("obs_ptr");
+    for (int t = 0; t < a->obs_ptr[d.n_obs]; ++t) if (a->obs_idx[t] < 0 || a->obs_idx[t] >= n) return bad("obs_idx");
+  }
+  BandDev b{};
+  b.n = n; b.n_obs = d.n_obs; b.xdim = d.xdim; b.gsize = (int)gsize; b.nAB = a->nAB; b.nL = (int)nL; b.nLx = a->nLx;
+  b.NSF = a->NSF; b.NSP = a->NSP; b.NX = a->NX; b.nfins = a->nfins; b.npf = a->npf; b.nif = a->nif; b.npost = a->npost;
+  b.post_g0 = a->nfins * (a->npf + a->nif); b.post_e0 = a->nfins * a->npf; b.post_L0 = a->nfins * a->npf * a->NSF;
+  b.offL = a->nAB; b.offLx = a->nAB + (int)nL; b.offY = a->nAB + (int)nL + a->nLx;
+  // records of the assembly pre-pass (fom_assemble_kernel): every value slot, so that special slots start at zero
+  std::vector<int> reci((size_t)a->nAB * 8, 0);
+  std::vector<double> recd((size_t)a->nAB * 5, 0.0);
+  for (int e = 0; e < a->nAB; ++e) {
+    const int t0 = a->ab_ptr[e], t1 = a->ab_ptr[e + 1];
+    reci[e * 8 + 0] = e; recd[e * 5 + 0] = a->ab_c0[e];
+    for (int k = 0; k < 4 && t0 + k < t1; ++k) { reci[e * 8 + 1 + k] = a->ab_idx[t0 + k]; recd[e * 5 + 1 + k] = a->ab_w[t0 + k]; }
+    reci[e * 8 + 5] = std::min(t0 + 4, t1); reci[e * 8 + 6] = t1;
+  }
+  FomDev& q = h->band_asm;
+  q = FomDev{};
+  q.xdim = d.xdim; q.gsize = (int)gsize; q.n_alist = a->nAB;
+  int rc = 0;
+  const int necp = a->ecp_ptr[a->npost], nobsnz = d.n_obs > 0 ? a->obs_ptr[d.n_obs] : 0;
+  if (!rc) rc = up(h->owned, &q.asm_rec_i, reci.data(), reci.size());
+  if (!rc) rc = up(h->owned, &q.asm_rec_d, recd.data(), recd.size());
+  if (!rc) rc = up(h->owned, &q.asm_idx, a->ab_idx, a->nterms);
+  if (!rc) rc = up(h->owned, &q.asm_w, a->ab_w, a->nterms);
+  if (!rc) rc = up(h->owned, &b.Fg, a->Fg, G);
+  if (!rc) rc = up(h->owned, &b.act, a->act, a->npost);
+  if (!rc) rc = up(h->owned, &b.lx_ptr, a->lx_ptr, a->npost + 1);
+  if (!rc) rc = up(h->owned, &b.ent_extra, a->ent_extra, a->npost);
+  if (!rc) rc = up(h->owned, &b.ecp_ptr, a->ecp_ptr, a->npost + 1);
+  if (!rc) rc = up(h->owned, &b.ecp_slot, a->ecp_slot, necp);
+  if (!rc) rc = up(h->owned, &b.ecp_off, a->ecp_off, necp);
+  if (!rc) rc = up(h->owned, &b.schur_off, a->schur_off, (size_t)a->nfins * nift);
+  if (!rc) rc = up(h->owned, &b.iface_elim, a->iface_elim, (size_t)a->nfins * a->nif);
+  if (!rc) rc = up(h->owned, &b.perm, a->perm, n);
+  if (!rc) rc = up(h->owned, &b.obs_ptr, a->obs_ptr, d.n_obs + 1);
+  if (!rc) rc = up(h->owned, &b.obs_idx, a->obs_idx, nobsnz);
+  if (!rc) rc = up(h->owned, &b.obs_w, a->obs_w, nobsnz);
+  if (rc) return rc;
+  b.on = 1;
+  h->band = b;
   return 0;
 }
 
@@ -883,7 +984,7 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   // register ranges, so they claim their slots before the small FOM waves fill the remaining ones
   // The FOM's short bandwidth-bound pre-pass (pack + assembly) runs first, alone; beside the projection kernel it
   // would crawl and hold back the interpreter, whose waves then start late.
-  const bool split = S <= fom_chunk_samples(fom->d);
+  const bool split = S <= fom_chunk_samples(fom->d, &fom->band);
   if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return rc;
   if (overlap && split) {                 // the ROM half starts after the pre-pass
     FR_HIP(hipEventRecord(rom->ev_fork, st));

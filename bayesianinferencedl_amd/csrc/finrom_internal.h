@@ -130,6 +130,17 @@ int launch_fom_assemble(const FomDev& p, const double* xT, int64_t nblk, double*
 int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st);
 int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hipStream_t st);
 
+// frontal band sweep (fom_band.hip, finrom_fom_set_band): per-sample workspace [AB | L | Lx | y -> w], sample-blocked
+struct BandDev {
+  int on = 0;
+  int n, n_obs, xdim, gsize, nAB, nL, nLx, NSF, NSP, NX, nfins, npf, nif, npost, post_g0, post_e0, post_L0;
+  int offL, offLx, offY;
+  const double* Fg; const int* act; const int* lx_ptr; const int* ent_extra; const int* ecp_ptr; const int* ecp_slot; const int* ecp_off;
+  const int* schur_off; const int* iface_elim; const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
+};
+bool band_supported(int NSF, int NSP, int NX);
+int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st);
+
 // ---- ROM ------------------------------------------------------------------------------
 constexpr int ROM_MAX_PHASES = 8;
 struct RomDev {

@@ -1,0 +1,335 @@
+// FOM throughput path: frontal band sweep with the front in REGISTERS (lane = sample).
+//
+// Replaces, for a whole batch, Fin.forward + Fin.qoi_operator (fom/forward_solve.py:270-291, 408-412) like the schedule
+// interpreter of fom_kernels.hip does, but without keeping the factor's working set in HBM.  The fin is a long thin domain:
+// ordered fin by fin (tip -> root, column by column) and then up the post row by row, the Cholesky factorisation only ever
+// touches a window of NS = B + 1 consecutive nodes (B = half bandwidth: m/4 + 1 in a fin, m + 1 in the post), i.e. a
+// triangle of NS (NS + 1) / 2 values per sample -- 105 doubles at m = 12.  That triangle lives in VGPRs; the window slides by
+// renaming slots cyclically (node t sits in slot t mod NS), and the loop over pivots is unrolled NS times so that every
+// register index is a compile-time constant.  Per pivot: 1/sqrt, B multiplies, B (B + 1) / 2 multiply-adds, B + 2 coalesced
+// 512-B stores (the finished column of L, 1/L_jj, y_j) -- no operand fetches.  The backward substitution streams the
+// columns back once.  HBM traffic per sample: the assembled entries (3 per node) + 2 x the factor; the interpreter moves
+// 5-6 x as much and executes ~14 instructions per multiply-add.
+//
+// Irregularity (bayesianinferencedl_amd/bandplan.py): eliminating a fin couples its interface nodes, which sit in
+// consecutive post ROWS; couplings that span more than B positions make the far node an *extra* front member.  Extras live
+// in LDS (their coupling to each window slot, diagonal, right-hand side, mutual couplings); a table says, per pivot, which
+// extra slots take part, and an extra is folded into the register window when its node enters it.  <= 4 alive at m = 12.
+//
+// All tables are wave-uniform and read with scalar loads; every index is validated on the host in finrom_fom_set_band.
+#include "finrom_internal.h"
+#include <type_traits>
+
+namespace finrom {
+
+namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+constexpr __device__ __host__ int tri(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct Io {                       // the wave's slice of the workspace as a buffer resource: SGPR offsets, no address arithmetic
+  __amdgpu_buffer_rsrc_t r; int lane8;
+  __device__ __forceinline__ double ld(int elem) const {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane8, elem * 512, 0));
+  }
+  template <int K> __device__ __forceinline__ double ldk(int elem) const {      // element elem + K, K folded into the offset field
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane8 + (K % 8) * 512, (elem + K / 8 * 8) * 512, 0));
+  }
+  __device__ __forceinline__ void st(double v, int elem) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, lane8, elem * 512, 0);
+  }
+  template <int K> __device__ __forceinline__ void stk(double v, int elem) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, lane8 + (K % 8) * 512, (elem + K / 8 * 8) * 512, 0);
+  }
+};
+
+// LDS state of the extras, per lane (index * 64 + lane): X[NXM][NS] | XD[NXM] | XY[NXM] | XX[pairs a > b] | WX[NXM]
+template <int NS, int NXM> struct XL {
+  static constexpr int X = 0, XD = NXM * NS, XY = XD + NXM, XX = XY + NXM, WX = XX + NXM * (NXM - 1) / 2, SIZE = WX + NXM;
+  static constexpr __device__ int xx(int a, int b) { return XX + (a > b ? a * (a - 1) / 2 + b : b * (b - 1) / 2 + a); }
+};
+
+struct PostTables {
+  const int* act; const int* lx_ptr; const int* ent_extra; const int* ecp_ptr; const int* ecp_slot; const int* ecp_off;
+};
+
+// ---- forward: factorisation fused with L y = F over one segment ----------------------------------------------------------
+template <int NS, bool POST, int NXM>
+__device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, double* __restrict__ xs, const double* __restrict__ Fg,
+                                           const PostTables& T, int g0, int e0, int npiv, int ntot, int L0,
+                                           double (&win)[NS * (NS + 1) / 2], double (&yw)[NS], int& bad) {
+  constexpr int B = NS - 1;
+  using L = XL<NS, NXM>;
+  static_for<0, NS*(NS + 1) / 2>([&](auto i) { win[decltype(i)::value] = 0.0; });
+  static_for<0, NS>([&](auto i) { yw[decltype(i)::value] = 0.0; });
+  if constexpr (POST) static_for<0, L::SIZE>([&](auto i) { xs[decltype(i)::value * 64] = 0.0; });
+
+  // node t enters the window in slot u = t mod NS (the slot its predecessor t - NS has just left)
+  auto enter = [&](auto uc, int t, double ab0, double ab1, double ab2) {
+    constexpr int u = decltype(uc)::value;
+    static_for<0, NS>([&](auto vc) { constexpr int v = decltype(vc)::value; if constexpr (v != u) win[tri(u, v)] = 0.0; });
+    double diag = 0.0, yv = 0.0;
+    if constexpr (POST) {
+      static_for<0, NXM>([&](auto sc) { xs[(L::X + decltype(sc)::value * NS + u) * 64] = 0.0; });
+      const int ex = T.ent_extra[t];
+      if (ex != 0) {                                     // the node was an extra: its state moves from LDS into the window
+        const int sl = ex - 1;
+        static_for<0, NS>([&](auto vc) {
+          constexpr int v = decltype(vc)::value;
+          if constexpr (v != u) win[tri(u, v)] = xs[(L::X + sl * NS + v) * 64];
+        });
+        diag = xs[(L::XD + sl) * 64]; yv = xs[(L::XY + sl) * 64];
+        static_for<0, NXM>([&](auto oc) {                // its couplings to the other extras become their window couplings
+          constexpr int o = decltype(oc)::value;
+          if (o != sl) {
+            const int a = o > sl ? o : sl, b = o > sl ? sl : o;
+            const int idx = L::XX + a * (a - 1) / 2 + b;
+            xs[(L::X + o * NS + u) * 64] = xs[idx * 64];
+            xs[idx * 64] = 0.0;
+          }
+        });
+        static_for<0, NS>([&](auto vc) { xs[(L::X + sl * NS + decltype(vc)::value) * 64] = 0.0; });
+        xs[(L::XD + sl) * 64] = 0.0; xs[(L::XY + sl) * 64] = 0.0;
+      }
+    }
+    win[tri(u, u)] = diag + ab0;
+    win[tri(u, (u + NS - 1) % NS)] += ab1;               // previous node (zero entry where there is none)
+    win[tri(u, (u + 1) % NS)] += ab2;                    // the node B positions back
+    yw[u] = yv + Fg[g0 + t];
+    if constexpr (POST) {
+      for (int c = T.ecp_ptr[t], c1 = T.ecp_ptr[t + 1]; c < c1; ++c)       // long-range couplings of this node: to extras
+        xs[(L::X + T.ecp_slot[c] * NS + u) * 64] += io.ld(T.ecp_off[c]);
+    }
+  };
+
+  static_for<0, NS>([&](auto uc) {                       // prologue: the first NS nodes enter an empty window
+    constexpr int u = decltype(uc)::value;
+    if (u < ntot) {
+      const int g = 3 * (g0 + u);
+      enter(uc, u, io.ld(g), io.ld(g + 1), io.ld(g + 2));
+    }
+  });
+
+  for (int p0 = 0; p0 < npiv; p0 += NS) {
+    static_for<0, NS>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int pp = p0 + u;
+      if (pp < npiv) {
+        const bool more = pp + NS < ntot;
+        double ab0 = 0.0, ab1 = 0.0, ab2 = 0.0;
+        if (more) {                                      // entries of the node that enters at the end of this step: in flight now
+          const int g = 3 * (g0 + pp + NS);
+          ab0 = io.ld(g); ab1 = io.ld(g + 1); ab2 = io.ld(g + 2);
+        }
+        const double d = win[tri(u, u)];
+        if (!(d > 0.0)) bad = 1;
+        double inv = __builtin_amdgcn_rsq(d);            // hardware estimate + two Newton steps (as the interpreter does)
+        inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+        inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+        double l[NS];
+        static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; l[s] = win[tri((u + s) % NS, u)] * inv; });
+        const int base = p.offL + L0 + pp * NS;
+        static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; io.template stk<s - 1>(l[s], base); });
+        io.template stk<NS - 1>(inv, base);
+        const double yp = yw[u] * inv;
+        io.st(yp, p.offY + e0 + pp);
+        static_for<1, NS>([&](auto sc) {
+          constexpr int s = decltype(sc)::value;
+          yw[(u + s) % NS] = fma(-l[s], yp, yw[(u + s) % NS]);
+          static_for<1, s + 1>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            win[tri((u + s) % NS, (u + t) % NS)] = fma(-l[s], l[t], win[tri((u + s) % NS, (u + t) % NS)]);
+          });
+        });
+        if constexpr (POST) {
+          const int am = T.act[pp];
+          if (am != 0) {
+            double le[NXM];
+            int k = p.offLx + T.lx_ptr[pp];
+            static_for<0, NXM>([&](auto sc) {
+              constexpr int sl = decltype(sc)::value;
+              le[sl] = 0.0;
+              if (am & (1 << sl)) {
+                const double v = xs[(L::X + sl * NS + u) * 64] * inv;
+                le[sl] = v;
+                io.st(v, k); ++k;
+                xs[(L::XY + sl) * 64] = fma(-v, yp, xs[(L::XY + sl) * 64]);
+                xs[(L::XD + sl) * 64] = fma(-v, v, xs[(L::XD + sl) * 64]);
+                static_for<1, NS>([&](auto tc) {
+                  constexpr int t = decltype(tc)::value;
+                  constexpr int a = (L::X + sl * NS + (u + t) % NS) * 64;
+                  xs[a] = fma(-v, l[t], xs[a]);
+                });
+              }
+            });
+            static_for<1, NXM>([&](auto ac) {
+              constexpr int a = decltype(ac)::value;
+              static_for<0, a>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                xs[L::xx(a, b) * 64] = fma(-le[a], le[b], xs[L::xx(a, b) * 64]);
+              });
+            });
+          }
+        }
+        if (more) enter(uc, pp + NS, ab0, ab1, ab2);
+        else static_for<0, NS>([&](auto vc) { win[tri(u, decltype(vc)::value)] = 0.0; });      // nobody enters: the slot is empty
+      }
+    });
+  }
+}
+
+// ---- backward: L^T w = y over one segment (w overwrites y), pivots in reverse -------------------------------------------------
+template <int NS, bool POST, int NXM>
+__device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, double* __restrict__ xs, const PostTables& T,
+                                            const int* __restrict__ iface, int e0, int npiv, int ntot, int L0) {
+  using L = XL<NS, NXM>;
+  double ww[NS];
+  static_for<0, NS>([&](auto i) { ww[decltype(i)::value] = 0.0; });
+  if constexpr (!POST) {                                 // the fin's trailing nodes are post nodes whose w is known
+    for (int t = 0; t < ntot - npiv; ++t) {
+      const double v = io.ld(p.offY + iface[t]);
+      const int su = (npiv + t) % NS;
+      static_for<0, NS>([&](auto uc) { constexpr int u = decltype(uc)::value; ww[u] = su == u ? v : ww[u]; });
+    }
+  } else {
+    static_for<0, NXM>([&](auto sc) { xs[(L::WX + decltype(sc)::value) * 64] = 0.0; });
+  }
+  for (int p0 = (npiv - 1) / NS * NS; p0 >= 0; p0 -= NS) {
+    static_for<0, NS>([&](auto rc) {
+      constexpr int u = NS - 1 - decltype(rc)::value;
+      const int pp = p0 + u;
+      if (pp < npiv) {
+        const int base = p.offL + L0 + pp * NS;
+        double lv[NS];
+        static_for<0, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; lv[s] = io.template ldk<s>(base); });   // l_1..l_B, 1/L_jj
+        double acc = io.ld(p.offY + e0 + pp);
+        static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; acc = fma(-lv[s - 1], ww[(u + s) % NS], acc); });
+        if constexpr (POST) {
+          const int am = T.act[pp];
+          if (am != 0) {
+            int k = p.offLx + T.lx_ptr[pp];
+            static_for<0, NXM>([&](auto sc) {
+              constexpr int sl = decltype(sc)::value;
+              if (am & (1 << sl)) { acc = fma(-io.ld(k), xs[(L::WX + sl) * 64], acc); ++k; }
+            });
+          }
+        }
+        const double wv = acc * lv[NS - 1];
+        io.st(wv, p.offY + e0 + pp);
+        ww[u] = wv;
+        if constexpr (POST) {
+          const int ex = T.ent_extra[pp];
+          if (ex != 0) xs[(L::WX + ex - 1) * 64] = wv;   // this node is an extra of earlier pivots
+        }
+      }
+    });
+  }
+}
+
+template <int NSF, int NSP, int NXM>
+__global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const double* __restrict__ Fg, const int* __restrict__ act,
+                                                      const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra,
+                                                      const int* __restrict__ ecp_ptr, const int* __restrict__ ecp_slot,
+                                                      const int* __restrict__ ecp_off, const int* __restrict__ schur_off,
+                                                      const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr,
+                                                      const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                      double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,
+                                                      int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double xlds[];
+  const int lane = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;
+  Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000), lane * 8};
+  double* xs = xlds + lane;
+  const PostTables T{act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off};
+  int bad = 0;
+  constexpr int NIFT = (NSF - 1) * NSF / 2;              // entries of a fin's Schur complement (q + 1 = NSF - 1 interface nodes)
+  {
+    double win[NSF * (NSF + 1) / 2], yw[NSF];
+    for (int f = 0; f < p.nfins; ++f) {
+      const int npiv = p.npf, ntot = p.npf + p.nif;
+      band_sweep<NSF, false, NXM>(p, io, xs, Fg, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      // what is left in the window is the fin's Schur complement on its interface nodes: add it to their entries in the post
+      int k = 0;
+      for (int t = 0; t < p.nif; ++t)
+        for (int s = 0; s <= t; ++s, ++k) {
+          const int a = (npiv + t) % NSF, b = (npiv + s) % NSF;
+          double v = 0.0;
+          static_for<0, NSF>([&](auto ac) {
+            static_for<0, decltype(ac)::value + 1>([&](auto bc) {
+              constexpr int ua = decltype(ac)::value, ub = decltype(bc)::value;
+              v = ((a == ua && b == ub) || (a == ub && b == ua)) ? win[tri(ua, ub)] : v;
+            });
+          });
+          const int off = schur_off[f * NIFT + k];
+          io.st(io.ld(off) + v, off);
+        }
+    }
+  }
+  {
+    double win[NSP * (NSP + 1) / 2], yw[NSP];
+    band_sweep<NSP, true, NXM>(p, io, xs, Fg, T, p.post_g0, p.post_e0, p.npost, p.npost, p.post_L0, win, yw, bad);
+  }
+  band_bsweep<NSP, true, NXM>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
+  for (int f = 0; f < p.nfins; ++f)
+    band_bsweep<NSF, false, NXM>(p, io, xs, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF);
+
+  const int64_t s = blk * 64 + lane;
+  const double nanv = __builtin_nan("");
+  if (bad) {                                             // not positive definite: NaN outputs and the flag, as the interpreter does
+    for (int i = 0; i < p.n; ++i) io.st(nanv, p.offY + i);
+    if (info != nullptr && s < S) atomicOr(&info[s], 1);
+  }
+  for (int o = 0; o < p.n_obs; ++o) {                    // QoI = B_obs w (fom :408-412), loads batched by 8
+    double q0 = 0.0, q1 = 0.0;
+    const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
+    for (int t = t0; t < t1; t += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = io.ld(p.offY + obs_idx[(t + u < t1) ? t + u : t1 - 1]);
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        q0 = fma((t + u < t1) ? obs_w[t + u] : 0.0, v[u], q0);
+        q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
+      }
+    }
+    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q0 + q1;
+  }
+}
+
+template <int NSF, int NSP>
+int launch_t(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
+  constexpr int NXM = 4;
+  const size_t lds = (size_t)XL<NSP, NXM>::SIZE * 64 * sizeof(double);
+  hipLaunchKernelGGL((fom_band_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.Fg, p.act, p.lx_ptr,
+                     p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx, p.obs_w,
+                     Gw, S, qoi, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+bool band_supported(int NSF, int NSP, int NX) {
+  return NX <= 4 && ((NSF == 3 && NSP == 6) || (NSF == 4 && NSP == 10) || (NSF == 5 && NSP == 14));
+}
+
+int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
+  if (nblk == 0) return 0;
+  ScopedKernelTimer t(K_FOM, st);
+  if (p.NSF == 3 && p.NSP == 6) return launch_t<3, 6>(p, Gw, nblk, S, qoi, info, st);
+  if (p.NSF == 4 && p.NSP == 10) return launch_t<4, 10>(p, Gw, nblk, S, qoi, info, st);
+  if (p.NSF == 5 && p.NSP == 14) return launch_t<5, 14>(p, Gw, nblk, S, qoi, info, st);
+  set_error("fom band sweep: unsupported window sizes");
+  return FINROM_ERR_UNSUPPORTED;
+}
+
+}  // namespace finrom

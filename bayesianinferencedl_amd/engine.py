@@ -10,7 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _ffi
-from ._ffi import FomSmallDesc, DeviceBuffer, FomDesc, FomGradDesc, RomDesc, check, f64, i32, lib
+from ._ffi import FomBandDesc, FomSmallDesc, DeviceBuffer, FomDesc, FomGradDesc, RomDesc, check, f64, i32, lib
 
 
 import os as _os
@@ -26,6 +26,9 @@ FUSED_X_MAX = int(_os.environ.get("FINROM_FUSED_X_MAX", "16"))
 # samples at m = 12 (value vector in LDS, one workgroup per CU), several thousand at m = 20 (value vector in L2).
 SMALL_MAX = int(_os.environ.get("FINROM_SMALL_MAX", "512"))
 SMALL_MAX_GLOBAL = int(_os.environ.get("FINROM_SMALL_MAX_GLOBAL", "4096"))
+# Batches beyond the small-batch schedule use the frontal band sweep (front in registers, csrc/fom_band.hip) when the mesh
+# has a band plan and the library has its window sizes; FINROM_NO_BAND=1 keeps the schedule interpreter.
+USE_BAND = _os.environ.get("FINROM_NO_BAND") is None
 
 
 def _is_torch(x):
@@ -96,8 +99,9 @@ class FomEngine:
     """Batched ``A(x) w = F`` + QoI (finrom_fom_*).  ``c0``/``W`` define the sparse-affine
     value map on the CSR pattern of A (see include/finrom.h)."""
 
-    def __init__(self, plan, c0_csr, W_csr, rhs, B_obs, pattern=None):
+    def __init__(self, plan, c0_csr, W_csr, rhs, B_obs, pattern=None, ops=None):
         self.plan = plan
+        self.band = None
         self.n = plan.n
         W_csr = sp.csr_matrix(W_csr)
         self.xdim = W_csr.shape[1]
@@ -141,6 +145,42 @@ class FomEngine:
                               col_ptr=I(plan.col_ptr), col_ent=I(plan.col_ent), col_row=I(plan.col_row),
                               lev_ptr_f=I(lpf), lev_rows_f=I(lrf), lev_ptr_b=I(lpb), lev_rows_b=I(lrb))
             check(lib().finrom_fom_set_small(self._h, C.byref(sd)), "finrom_fom_set_small")
+        if USE_BAND and ops is not None:
+            self._enable_band(ops, c0_csr, W_csr, rhs, B_obs)
+
+    def _enable_band(self, ops, c0_csr, W_csr, rhs, B_obs):
+        """Install the frontal band sweep (finrom_fom_set_band) when the mesh has a band plan and the library was built with
+        its window sizes; otherwise the handle keeps the interpreter."""
+        bp = ops.band_plan()
+        if bp is None:
+            return
+        c0, ptr, idx, w = bp.ab_table(c0_csr, W_csr)
+        F = np.asarray(rhs, dtype=np.float64)
+        Fg = np.zeros(bp.G)
+        for seg in bp.fin_segs + [bp.post_seg]:
+            Fg[seg.g0:seg.g0 + seg.npiv] = F[bp.perm[seg.e0:seg.e0 + seg.npiv]]
+        Bp = sp.csr_matrix(np.asarray(B_obs)[:, bp.perm]) if not sp.issparse(B_obs) else sp.csr_matrix(B_obs)[:, bp.perm]
+        optr, oidx, ow = _csr_rows(Bp)
+        nif = bp.q + 1
+        schur = np.asarray([[off for _, _, off in tg] for tg in bp.schur_target], np.int32)
+        keep = []
+
+        def I(a):
+            a, p = i32(a); keep.append(a); return p
+
+        def D(a):
+            a, p = f64(a); keep.append(a); return p
+        d = FomBandDesc(NSF=bp.NSF, NSP=bp.NSP, NX=bp.NX, nfins=bp.nfins, npf=bp.npf, nif=nif, npost=bp.npost, nAB=bp.nAB,
+                        nterms=len(idx), nLx=bp.nLx, ab_c0=D(c0), ab_ptr=I(ptr), ab_idx=I(idx), ab_w=D(w), Fg=D(Fg),
+                        act=I(bp.act), lx_ptr=I(bp.lx_ptr), ent_extra=I(bp.ent_extra),
+                        ecp_ptr=I(bp.ecp_ptr), ecp_slot=I(bp.ecp_slot), ecp_off=I(bp.ecp_off),
+                        schur_off=I(schur), iface_elim=I(bp.iface_elim), perm=I(bp.perm),
+                        obs_ptr=I(optr), obs_idx=I(oidx), obs_w=D(ow))
+        rc = lib().finrom_fom_set_band(self._h, C.byref(d))
+        if rc == -4:                                     # FINROM_ERR_UNSUPPORTED: window sizes not built in -> interpreter
+            return
+        check(rc, "finrom_fom_set_band")
+        self.band = bp
 
     def solve(self, X, want_w=False):
         b = _Batch(X, self.xdim)

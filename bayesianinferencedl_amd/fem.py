@@ -323,6 +323,18 @@ class FinOperators:
         E[4, 4] = 1.0
         self.E59 = E
 
+    def band_plan(self):
+        """Plan of the frontal band sweep (bandplan.py) for this mesh, or None if the operator does not have the structure
+        it assumes.  Entries that are zero in EVERY operator table (the hypotenuse couplings) are left out of the band."""
+        if not hasattr(self, "_band_plan"):
+            from .bandplan import BandPlan, BandPlanError, nonzero_entries
+            try:
+                self._band_plan = BandPlan(self.mesh, self.indptr, self.indices,
+                                           nonzero_entries(self.robin_vals, self.W_field, list(self.sub_vals)))
+            except BandPlanError:
+                self._band_plan = None
+        return self._band_plan
+
     # -- convenience ----------------------------------------------------------
     def csr(self, vals):
         return sp.csr_matrix((vals, self.indices, self.indptr), shape=(self.n, self.n))

@@ -70,7 +70,7 @@ class Fin:
                 W = sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9 @ ops.E59))
             else:
                 raise KeyError(kind)
-            self._engines[kind] = FomEngine(self._plan, ops.robin_vals, W, ops.F, self.B_obs, pattern=(ops.indptr, ops.indices))
+            self._engines[kind] = FomEngine(self._plan, ops.robin_vals, W, ops.F, self.B_obs, pattern=(ops.indptr, ops.indices), ops=ops)
         return self._engines[kind]
 
     # ---- batched extensions (new, additive) ---------------------------------------------

@@ -130,7 +130,7 @@ class AffineROMFin:
         """'Averaged FOM' (:237-258) for a batch of nodal fields."""
         if self._fom is None:
             ops = self.ops
-            self._fom = FomEngine(self._plan, ops.robin_vals, sp.csr_matrix(ops.sub_vals.T), ops.F, self.B_obs)
+            self._fom = FomEngine(self._plan, ops.robin_vals, sp.csr_matrix(ops.sub_vals.T), ops.F, self.B_obs, ops=ops)
         return self._fom.solve(self.subfin_avg_batch(K), want_w=want_w)
 
     def _ensure_gradient(self):

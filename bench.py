@@ -56,7 +56,9 @@ def parse():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / sharding rehearsal without a GPU: ranks start, build their shard of the globally keyed "
                          "inputs, gather a stand-in over gloo and rank 0 prints the JSON line with value = null")
-    return ap.parse_args()
+    # rank processes get their arguments through the environment: torch.distributed.run's own parser chokes on script
+    # options that are prefixes of its own (--m)
+    return ap.parse_args(json.loads(os.environ["BENCH_ARGV"]) if "BENCH_ARGV" in os.environ else None)
 
 
 def launch_ranks(args):
@@ -69,8 +71,8 @@ def launch_ranks(args):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_LAUNCHED="1")
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_ARGV=json.dumps(sys.argv[1:]))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
     raise SystemExit(subprocess.run(cmd, env=env).returncode)

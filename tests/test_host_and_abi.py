@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in finrom.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib.finrom_version.restype = ctypes.c_int
-    assert lib.finrom_version() == 5
+    assert lib.finrom_version() == 6
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -251,3 +251,27 @@ def test_fused_assembly_stream_replays_to_the_same_solution(spaces, params):
     w = np.empty(ops.n); w[plan.perm] = wp
     ref = spl.spsolve(ops.csr(ops.fom_values(lift @ x)).tocsc(), ops.F)
     assert np.linalg.norm(w - ref) < 1e-12 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("m", [4, 8, 12])
+def test_band_plan_replay_solves_the_fom(spaces, m):
+    """bandplan.py: fin-by-fin, then up the post -- the tables of the frontal band sweep (windows of NS slots renamed
+    cyclically, fin Schur complements added to the post's entries, long-range couplings carried as extras) replayed in NumPy
+    with the device kernel's data flow must solve A(k) w = F for every operator table the engines use."""
+    import scipy.sparse as sp
+    ops = spaces(m).operators()
+    bp = ops.band_plan()
+    assert bp is not None and (bp.NSF, bp.NSP) == (m // 4 + 2, m + 2) and bp.NX <= 4
+    assert sorted(bp.perm.tolist()) == list(range(ops.n))
+    assert bp.lx_ptr[-1] == bp.nLx and bp.nLx == sum(bin(int(a)).count("1") for a in bp.act)
+    rng = np.random.default_rng(m)
+    for W, x in ((ops.W_field, np.exp(0.5 * rng.standard_normal(ops.n))),
+                 (sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9 @ ops.E59)), rng.uniform(0.1, 10.0, 5)),
+                 (sp.csr_matrix(ops.sub_vals.T), rng.uniform(0.1, 10.0, 9))):
+        c0, ptr, idx, w = bp.ab_table(ops.robin_vals, W)
+        AB = c0 + np.array([(w[ptr[e]:ptr[e + 1]] * x[idx[ptr[e]:ptr[e + 1]]]).sum() for e in range(bp.nAB)])
+        sol = bp.replay(AB, ops.F)
+        ref = spl.spsolve(ops.csr(ops.robin_vals + sp.csr_matrix(W) @ x).tocsc(), ops.F)
+        assert np.linalg.norm(sol - ref) < 1e-12 * np.linalg.norm(ref)
+    with pytest.raises(np.linalg.LinAlgError):
+        bp.replay(-AB, ops.F)
