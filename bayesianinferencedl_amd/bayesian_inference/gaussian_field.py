@@ -33,4 +33,6 @@ _KERNELS = {
 def make_cov_chol(V, kern_type='m52', length=1.6):
     xy = V.tabulate_dof_coordinates().reshape((-1, 2))[V.dofmap().dofs(), :]
     kern = _KERNELS.get(kern_type, _KERNELS['m32'])
-    return scipy.linalg.cholesky(kern(squareform(pdist(xy)), length))
+    from ..fem import deterministic_blas
+    with deterministic_blas():           # one LAPACK thread: the same factor, bit for bit, in every rank of a multi-GPU run
+        return scipy.linalg.cholesky(kern(squareform(pdist(xy)), length))

@@ -86,7 +86,7 @@ struct finrom_fom_s {
 struct finrom_rom_s {
   RomDev d{};
   std::vector<void*> owned;
-  Scratch Ar, Br, theta, qtmp, vw;
+  Scratch Ar, Br, theta, qtmp, vw, ticket;
   int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
   RomGramDev gram;                     // offline/online form (finrom_rom_set_gram); gram.h is filled at create
   int projection = FINROM_PROJECTION_DIRECT;
@@ -767,7 +767,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
 void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release();
+  h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release(); h->ticket.release();
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -833,7 +833,8 @@ static int rom_project(finrom_rom_t h, const double* theta, int64_t S, int facto
                        double* w_r = nullptr, double* qoi_r = nullptr) {
   if (h->projection == FINROM_PROJECTION_GRAM)
     return launch_rom_gram(h->d, h->gram, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r);
-  return launch_rom_proj(h->d, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r);
+  if (h->ticket.reserve(4096 * sizeof(int))) return FINROM_ERR_NOMEM;
+  return launch_rom_proj(h->d, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r, (int*)h->ticket.p);
 }
 
 int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r, double* qoi_r, double* A_r,

@@ -294,7 +294,7 @@ static int launch_proj_lds(const RomDev& p, const double* theta, int64_t S, doub
 }
 
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
-                    hipStream_t st, double* w_r, double* qoi_r) {
+                    hipStream_t st, double* w_r, double* qoi_r, int* cu_ticket) {
   // factor: 0 = write A_r, 1 = write its Cholesky factor (NB <= 6), 2 = also solve and write only w_r / qoi_r (NB <= 5)
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_PROJ, st);
@@ -317,7 +317,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
                                dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r); } break;
   switch (p.NB) {
     case 1: case 2: case 3: case 4: case 5:      // own translation unit (-O2)
-      return launch_rom_proj_single(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+      return launch_rom_proj_single(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, cu_ticket);
     FR_CASE(6, 1)
     FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
     FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 8)   // r > 192: 8 waves per sample so that a wave's tiles fit architectural VGPRs

@@ -324,39 +324,16 @@ def main():
         fl = flops_per_pair(ops, plan, solver_r, pairs.n_obs, pairs.xdim)
         total_pairs = world * S * args.steps
         ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in prof.items()}       # avg ms per launch
+        launches = {k: v[0] for k, v in prof.items()}
         # dominant kernel by measured time
         cand = {k: v[1] for k, v in prof.items()}
         dom = max(cand, key=cand.get) if any(cand.values()) else "rom_proj_mfma"
-        roof = None
-        traffic = measured_traffic(dom, f"{args.params}/m{args.m}/r{args.r}/S{S}")
         if args.projection == "offline_online":
             npairs = solver_r._rom.gram_pairs
             fl["syrk_sym"] = npairs * args.r * (args.r + 1)          # multiply-adds of the block sum, symmetric half
             fl["psi"] = 0
             fl["rhs"] = 2 * 10 * args.r
-            if dom == "rom_proj_mfma":                               # (only if the FOM half is not the longer one)
-                dom = "fom_chol_solve" if ms.get("fom_chol_solve", 0) > 0 else dom
-        if dom == "rom_proj_mfma" and ms[dom] > 0:
-            # what the projection kernel computes: psi rows from the sparse tables, the symmetric half of psi^T psi, psi^T F and --
-            # for r <= 80, where the reduced system is factored and solved in the same kernel -- r^3/3 + 2 r^2 + the reduced QoI
-            alg = S * (fl["syrk_sym"] + 2 * solver_r._rom.nterms * args.r + fl["rhs"]
-                       + (fl["reduced_solve"] + 2 * pairs.n_obs * args.r if args.r <= 80 else 0))
-            ach = alg / (ms[dom] * 1e-3) / 1e12
-            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic,
-                    "algorithmic_flops_per_launch": alg, "avg_launch_ms": ms[dom]}
-        elif ms.get(dom, 0) > 0:
-            # FOM interpreter: per sample one 8-B operand per multiply-add of the schedule
-            # (the other operand sits in LDS), L / 1/L_ii / y / w each written once, x read once
-            st = solver._engine("field" if args.params == "field" else args.params)._streams
-            nload_f = int((st["fwd"][1] >= 0).sum())                 # ops that fetch a global operand
-            nload_b = int((st["bwd"][0] == 1).sum() * 2 + (st["bwd"][0] > 1).sum())
-            per_sample = 8 * (nload_f + nload_b + 2 * plan.nnzL + 4 * ops.n + pairs.xdim + pairs.n_obs)
-            alg = S * per_sample
-            ach = alg / (ms[dom] * 1e-3) / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
-                    "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms[dom]}
+        roof = roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl)
 
         cpu = None
         if world == 1 and args.cpu_samples > 0:
@@ -522,6 +499,66 @@ def hmc_cpu_baseline(args, phi, model, data, K0, res):
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "evals/s", "cores": 1, "kind": "port",
             "sample": f"{done} evaluations of oracle.grad_romml_oracle at the chains' start points, 1 thread"}
+
+
+def roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl):
+    """Roofline object of the dominant kernel `dom` (a profile slot of the library), chosen BY KERNEL: what it computes or
+    must move per launch over its measured average launch time.  A slot that is launched several times per step
+    (workspace pieces) processes S / pieces samples per launch."""
+    if not ms.get(dom, 0) > 0:
+        return None
+    r, n, n_obs = args.r, ops.n, pairs.n_obs
+    rp = (r + 15) // 16 * 16
+    per_launch = S * args.steps / max(launches.get(dom, args.steps), 1)          # samples one launch processes
+    t = ms[dom] * 1e-3
+    key = f"{args.params}/m{args.m}/r{args.r}/S{S}"
+
+    def hbm(bytes_per_sample, model):
+        alg = per_launch * bytes_per_sample
+        traffic = measured_traffic(dom, key)
+        ach = alg / t / 1e9
+        return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms[dom], "model": model}
+
+    def mfma(flops_per_sample, model):
+        alg = per_launch * flops_per_sample
+        ach = alg / t / 1e12
+        return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": measured_traffic(dom, key), "algorithmic_flops_per_launch": alg,
+                "avg_launch_ms": ms[dom], "model": model}
+
+    if dom == "rom_proj_mfma" and args.projection == "direct":
+        # psi rows from the sparse tables, the symmetric half of psi^T psi, psi^T F on the ROOT rows only (F = 0 elsewhere) and --
+        # for r <= 80, where the reduced system is factored and solved in the same kernel -- r^3/3 + 2 r^2 + the reduced QoI
+        nroot = int(np.count_nonzero(ops.F))
+        f = fl["syrk_sym"] + 2 * solver_r._rom.nterms * r + 2 * nroot * r
+        if r <= 80:
+            f += fl["reduced_solve"] + 2 * n_obs * r
+        return mfma(f, "n r (r+1) + 2 nterms r + 2 nroot r (+ r^3/3 + 2 r^2 + 2 n_obs r for r <= 80)")
+    if dom == "rom_proj_mfma":
+        # offline/online form: the block sum streams tile images out of L2; what HAS to cross HBM is theta in, w_r + qoi_r out
+        return hbm(8 * (9 + r + n_obs), "compulsory bytes only (theta in; w_r, qoi_r out): the block images are L2 traffic")
+    if dom == "fom_chol_solve":
+        eng = solver._engine("field" if args.params == "field" else args.params)
+        if eng.band is not None:
+            bp = eng.band
+            # frontal band sweep: value slots read once, every column of L (+ extras) written once and read once, y written and
+            # read, w written, QoI out -- nothing else leaves the registers
+            return hbm(8 * (bp.nAB + 2 * bp.nL + 2 * bp.nLx + 3 * n + n_obs), "AB + 2 (L + Lx) + 3 n + n_obs doubles per sample")
+        # interpreter: lower bound -- L written once and read once, y / w, parameters; its operand re-fetches come on top
+        return hbm(8 * (2 * plan.nnzL + 4 * n + pairs.xdim + n_obs), "lower bound: 2 nnz(L) + 4 n + xdim + n_obs doubles per sample")
+    if dom == "rom_reduced_solve":
+        # wide bases: the packed A_r is read and its factor written by the blocked Cholesky, the factor is read again by the
+        # substitutions (at least once), B_r in, w_r and qoi_r out
+        npk = rp * (rp + 1) // 2
+        return hbm(8 * (3 * npk + rp + r + n_obs), "lower bound: 3 packed triangles + B_r + w_r + qoi_r per sample")
+    if dom == "fom_assemble":
+        eng = solver._engine("field" if args.params == "field" else args.params)
+        nval = eng.band.nAB if eng.band is not None else len(eng._streams["a_list"])
+        return hbm(8 * (nval + pairs.xdim), "value slots written + parameters read")
+    if dom == "sampler_gemm_exp":
+        return mfma(n * n, "n^2 (triangular half of the dense GEMM)")
+    return hbm(8 * (pairs.xdim + 2 * n_obs), "compulsory bytes")
 
 
 def dry_run(args, rank, world):

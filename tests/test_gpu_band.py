@@ -28,7 +28,9 @@ def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
     old = E.USE_BAND
     try:
         E.USE_BAND = False
-        fin_i = Fin(V)                                    # interpreter-only engines
+        fin_i = Fin(V)                                    # interpreter-only engines (created lazily: force them now)
+        for params in ("field", "nine", "five"):
+            assert fin_i._engine(params).band is None
     finally:
         E.USE_BAND = old
     for params, dim in (("field", prob.n), ("nine", 9), ("five", 5)):

@@ -30,3 +30,20 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "pairs/s"
     assert d["config"]["failed_samples"] == 0
+
+
+@pytest.mark.parametrize("argv", [["--params", "nine", "--r", "120", "--samples", "4096"],
+                                  ["--params", "field", "--m", "20", "--r", "200", "--samples", "1024"],
+                                  ["--projection", "offline_online", "--samples", "8192"],
+                                  ["--params", "nine", "--r", "120", "--samples", "4096", "--projection", "offline_online"]])
+def test_bench_roofline_is_a_fraction_for_every_config(argv):
+    """The roofline object is chosen by kernel (projection / blocked reduced solve / FOM sweep ...): whatever kernel dominates a
+    configuration, 0 < frac <= 1 (the interpreter's no-cache byte model applied to another kernel gave 1.21)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-samples", "0",
+                        "--no-other", "--no-host-io"] + argv, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    rf = d["roofline"]
+    assert rf is not None and 0 < rf["frac"] <= 1.0, rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel"] in d["kernels_avg_ms"] and "model" in rf
+    assert d["config"]["failed_samples"] == 0
