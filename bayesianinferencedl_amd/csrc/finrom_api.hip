@@ -652,7 +652,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   RomDev& d = h->d;
   d.n = a->n; d.r = r; d.rp = rp; d.NB = NB; d.P = a->P; d.n_obs = a->n_obs;
   d.solve_in_lds = rp <= 176 ? 1 : 0;
-  d.clock_probe = getenv("FINROM_CLOCK_PROBE") != nullptr; d.trace = nullptr;
+  d.clock_probe = getenv("FINROM_CLOCK_PROBE") != nullptr ? std::max(1, atoi(getenv("FINROM_CLOCK_PROBE"))) : 0; d.trace = nullptr;
   d.n_phases = 0;
   std::vector<double> tv; std::vector<int> pidx;
   auto push_slot = [&](std::vector<double>& T, std::vector<int>& Pi, const std::vector<int>& rows4, int t) {
@@ -964,7 +964,11 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     theta = (double*)rom->theta.p;
   }
   // the two halves run on two streams (FINROM_NO_OVERLAP / finrom_set_overlap(0): in turn, for per-kernel profiling)
-  const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr;
+  // With the band sweep as the FOM half there is nothing to gain from running the halves side by side: it is HBM-bound at one
+  // 300-register wave per SIMD and evicts the projection's second wave (measured: 36.2 ms overlapped vs 31.9 ms in turn per
+  // 100k samples); the interpreter (latency-bound, 56 registers) does overlap.  FINROM_FORCE_OVERLAP=1 overrides.
+  const bool band_fom = fom->band.on && getenv("FINROM_NO_BAND") == nullptr && !(fom->small.small_max > 0 && S <= fom->small.small_max);
+  const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr && (!band_fom || getenv("FINROM_FORCE_OVERLAP") != nullptr);
   hipStream_t side = overlap ? rom->side : st;
   const bool tracing = trace_prefix() != nullptr;
   if (tracing) {

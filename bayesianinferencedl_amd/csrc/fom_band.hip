@@ -118,35 +118,40 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
     }
   });
 
-  for (int p0 = 0; p0 < npiv; p0 += NS) {
-    static_for<0, NS>([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      const int pp = p0 + u;
-      if (pp < npiv) {
+  // Main loop, software-pipelined: step s first eliminates pivot s - RF (whose entering node's three entries were requested RF
+  // steps ago and sit in ring slot s mod RF), then requests the entries for pivot s into the slot it has just emptied.  RF
+  // divides NS, so with the loop unrolled NS times ring slot and window slot are both compile-time constants.
+  constexpr int RF = (NS % 2 == 0) ? 2 : NS;
+  double ab[RF][3];
+  static_for<0, RF>([&](auto i) { ab[decltype(i)::value][0] = ab[decltype(i)::value][1] = ab[decltype(i)::value][2] = 0.0; });
+  for (int s0 = 0; s0 < npiv + RF; s0 += NS) {
+    static_for<0, NS>([&](auto usc) {
+      constexpr int us = decltype(usc)::value;
+      constexpr int u = (us + NS - RF % NS) % NS;        // window slot of pivot s - RF
+      constexpr int rs = us % RF;                        // ring slot (of pivot s - RF and, afterwards, of pivot s)
+      const int sidx = s0 + us;
+      const int pp = sidx - RF;
+      if (pp >= 0 && pp < npiv) {
         const bool more = pp + NS < ntot;
-        double ab0 = 0.0, ab1 = 0.0, ab2 = 0.0;
-        if (more) {                                      // entries of the node that enters at the end of this step: in flight now
-          const int g = 3 * (g0 + pp + NS);
-          ab0 = io.ld(g); ab1 = io.ld(g + 1); ab2 = io.ld(g + 2);
-        }
+        const double ab0 = ab[rs][0], ab1 = ab[rs][1], ab2 = ab[rs][2];
         const double d = win[tri(u, u)];
         if (!(d > 0.0)) bad = 1;
         double inv = __builtin_amdgcn_rsq(d);            // hardware estimate + two Newton steps (as the interpreter does)
         inv = inv * fma(-0.5 * d * inv, inv, 1.5);
         inv = inv * fma(-0.5 * d * inv, inv, 1.5);
         double l[NS];
-        static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; l[s] = win[tri((u + s) % NS, u)] * inv; });
+        static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; l[s_] = win[tri((u + s_) % NS, u)] * inv; });
         const int base = p.offL + L0 + pp * NS;
-        static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; io.template stk<s - 1>(l[s], base); });
+        static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; io.template stk<s_ - 1>(l[s_], base); });
         io.template stk<NS - 1>(inv, base);
         const double yp = yw[u] * inv;
         io.st(yp, p.offY + e0 + pp);
         static_for<1, NS>([&](auto sc) {
-          constexpr int s = decltype(sc)::value;
-          yw[(u + s) % NS] = fma(-l[s], yp, yw[(u + s) % NS]);
-          static_for<1, s + 1>([&](auto tc) {
+          constexpr int s_ = decltype(sc)::value;
+          yw[(u + s_) % NS] = fma(-l[s_], yp, yw[(u + s_) % NS]);
+          static_for<1, s_ + 1>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            win[tri((u + s) % NS, (u + t) % NS)] = fma(-l[s], l[t], win[tri((u + s) % NS, (u + t) % NS)]);
+            win[tri((u + s_) % NS, (u + t) % NS)] = fma(-l[s_], l[t], win[tri((u + s_) % NS, (u + t) % NS)]);
           });
         });
         if constexpr (POST) {
@@ -179,8 +184,12 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
             });
           }
         }
-        if (more) enter(uc, pp + NS, ab0, ab1, ab2);
+        if (more) enter(std::integral_constant<int, u>{}, pp + NS, ab0, ab1, ab2);
         else static_for<0, NS>([&](auto vc) { win[tri(u, decltype(vc)::value)] = 0.0; });      // nobody enters: the slot is empty
+      }
+      if (sidx < npiv && sidx + NS < ntot) {             // entries of the node that enters after pivot s: in flight for RF steps
+        const int g = 3 * (g0 + sidx + NS);
+        ab[rs][0] = io.ld(g); ab[rs][1] = io.ld(g + 1); ab[rs][2] = io.ld(g + 2);
       }
     });
   }
@@ -202,32 +211,44 @@ __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, doub
   } else {
     static_for<0, NXM>([&](auto sc) { xs[(L::WX + decltype(sc)::value) * 64] = 0.0; });
   }
-  for (int p0 = (npiv - 1) / NS * NS; p0 >= 0; p0 -= NS) {
+  // Software-pipelined like the forward sweep: the column of pivot v (NS values) and y_v were requested RB steps ago into ring
+  // slot v mod RB (RB divides NS: compile-time slots); after using them the step requests pivot v - RB into the same slot.
+  // RB columns in flight per wave (7 x 7.5 KB in the post at m = 12) is what keeps HBM busy with one wave per SIMD.
+  constexpr int RB = NS % 7 == 0 ? 7 : NS % 5 == 0 ? 5 : NS % 3 == 0 ? 3 : NS % 2 == 0 ? 2 : NS;
+  double lb[RB][NS + 1];
+  const int vtop = npiv - 1 + RB;
+  for (int p0 = vtop / NS * NS; p0 >= 0; p0 -= NS) {
     static_for<0, NS>([&](auto rc) {
       constexpr int u = NS - 1 - decltype(rc)::value;
-      const int pp = p0 + u;
-      if (pp < npiv) {
-        const int base = p.offL + L0 + pp * NS;
-        double lv[NS];
-        static_for<0, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; lv[s] = io.template ldk<s>(base); });   // l_1..l_B, 1/L_jj
-        double acc = io.ld(p.offY + e0 + pp);
-        static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; acc = fma(-lv[s - 1], ww[(u + s) % NS], acc); });
-        if constexpr (POST) {
-          const int am = T.act[pp];
-          if (am != 0) {
-            int k = p.offLx + T.lx_ptr[pp];
-            static_for<0, NXM>([&](auto sc) {
-              constexpr int sl = decltype(sc)::value;
-              if (am & (1 << sl)) { acc = fma(-io.ld(k), xs[(L::WX + sl) * 64], acc); ++k; }
-            });
+      constexpr int rs = u % RB;
+      const int v = p0 + u;
+      if (v <= vtop) {
+        if (v < npiv) {
+          double acc = lb[rs][NS];
+          static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; acc = fma(-lb[rs][s - 1], ww[(u + s) % NS], acc); });
+          if constexpr (POST) {
+            const int am = T.act[v];
+            if (am != 0) {
+              int k = p.offLx + T.lx_ptr[v];
+              static_for<0, NXM>([&](auto sc) {
+                constexpr int sl = decltype(sc)::value;
+                if (am & (1 << sl)) { acc = fma(-io.ld(k), xs[(L::WX + sl) * 64], acc); ++k; }
+              });
+            }
+          }
+          const double wv = acc * lb[rs][NS - 1];
+          io.st(wv, p.offY + e0 + v);
+          ww[u] = wv;
+          if constexpr (POST) {
+            const int ex = T.ent_extra[v];
+            if (ex != 0) xs[(L::WX + ex - 1) * 64] = wv;   // this node is an extra of earlier pivots
           }
         }
-        const double wv = acc * lv[NS - 1];
-        io.st(wv, p.offY + e0 + pp);
-        ww[u] = wv;
-        if constexpr (POST) {
-          const int ex = T.ent_extra[pp];
-          if (ex != 0) xs[(L::WX + ex - 1) * 64] = wv;   // this node is an extra of earlier pivots
+        const int nx = v - RB;
+        if (nx >= 0 && nx < npiv) {
+          const int base = p.offL + L0 + nx * NS;
+          static_for<0, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; lb[rs][s] = io.template ldk<s>(base); });   // l_1..l_B, 1/L_jj
+          lb[rs][NS] = io.ld(p.offY + e0 + nx);
         }
       }
     });

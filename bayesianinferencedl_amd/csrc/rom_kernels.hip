@@ -179,7 +179,7 @@ __device__ __forceinline__ void lds_chunk_compute(const double* __restrict__ buf
 }
 
 template <int NB, int WPB>      // WPB waves (= samples) per workgroup share each staged chunk
-__global__ __launch_bounds__(64 * WPB, 1) void rom_proj_lds_kernel(RomDev p, const int* __restrict__ ch_nt,
+__global__ __launch_bounds__(64 * WPB, WPB == 4 ? 3 : 1) void rom_proj_lds_kernel(RomDev p, const int* __restrict__ ch_nt,
                                                               const int* __restrict__ ch_nks,
                                                               const int* __restrict__ ch_off,
                                                               const int* __restrict__ ch_bytes,

@@ -18,11 +18,14 @@ constexpr int ROM_MAX_NT = 4;
 template <int NB>
 __device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const int* __restrict__ pidx, int slot, int nt,
                                            int rp, int q, int c, double (&raw)[ROM_MAX_NT][NB], int (&pi)[ROM_MAX_NT]) {
+  // theta indices of ALL four possible terms first (slots beyond nt belong to the following k-steps or to the padding: valid
+  // indices, their theta is read and not used): the LDS reads of theta can then be issued together, ahead of the table values
+#pragma unroll
+  for (int t = 0; t < ROM_MAX_NT; ++t) pi[t] = pidx[(slot + t) * 4 + q];
 #pragma unroll
   for (int t = 0; t < ROM_MAX_NT; ++t) {
     if (t < nt) {                                  // wave-uniform
       const int row = (slot + t) * 4 + q;
-      pi[t] = pidx[row];
       const double* src = tv + (int64_t)row * rp + c;
 #pragma unroll
       for (int b = 0; b < NB; ++b) raw[t][b] = src[16 * b];
@@ -37,10 +40,11 @@ __device__ __forceinline__ void load_kstep_own(const double* __restrict__ tv, co
                                                int (&pi)[ROM_MAX_NT]) {
   constexpr int NOWN = (NB - W + NW - 1) / NW;
 #pragma unroll
+  for (int t = 0; t < ROM_MAX_NT; ++t) pi[t] = pidx[(slot + t) * 4 + q];
+#pragma unroll
   for (int t = 0; t < ROM_MAX_NT; ++t) {
     if (t < nt) {                                  // wave-uniform
       const int row = (slot + t) * 4 + q;
-      pi[t] = pidx[row];
       const double* src = tv + (int64_t)row * rp + c;
 #pragma unroll
       for (int j = 0; j < NOWN; ++j) raw[t][j] = src[16 * (W + j * NW)];
@@ -228,6 +232,8 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 #pragma unroll
   for (int t = 0; t < NTL; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 
+  const int rp_ld = p.clock_probe == 2 ? 0 : p.rp;      // FINROM_CLOCK_PROBE=2 (timing experiment, results are garbage): every
+                                                       // table fetch hits the same four rows -> no L2 traffic, same instructions
   if constexpr (NW > 1) {
     // The NW waves of a sample (= the workgroup) share the slab through LDS: wave W builds its own blocks from the tables
     // (1/NW of the loads and multiply-adds: stand-alone, every wave rebuilding the whole slab saturates the CU's L1 path),
@@ -251,12 +257,14 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
         double own[NOWN];
 #pragma unroll
         for (int j = 0; j < NOWN; ++j) own[j] = 0.0;
+        double thp[ROM_MAX_NT];
+#pragma unroll
+        for (int t = 0; t < ROM_MAX_NT; ++t) thp[t] = thw[pi[t]];      // four LDS reads in flight together
 #pragma unroll
         for (int t = 0; t < ROM_MAX_NT; ++t) {
           if (t < nt) {
-            const double thp = thw[pi[t]];
 #pragma unroll
-            for (int j = 0; j < NOWN; ++j) own[j] = fma(thp, raw[t][j], own[j]);
+            for (int j = 0; j < NOWN; ++j) own[j] = fma(thp[t], raw[t][j], own[j]);
           }
         }
         double* buf = slab + par * (NB * 64);
@@ -280,7 +288,7 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     int pi[ROM_MAX_NT];
     int ph = 0;
     while (ph < p.n_phases && p.phase_ks0[ph] >= p.phase_ks1[ph]) ++ph;
-    if (ph < p.n_phases) load_kstep<NB>(p.tv, p.pidx, p.phase_slot0[ph], p.phase_nt[ph], p.rp, q, c, raw, pi);
+    if (ph < p.n_phases) load_kstep<NB>(p.tv, p.pidx, p.phase_slot0[ph], p.phase_nt[ph], rp_ld, q, c, raw, pi);
 #pragma unroll 1
     for (; ph < p.n_phases; ++ph) {
       const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph], nt = p.phase_nt[ph];
@@ -294,18 +302,20 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
         double v[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) v[b] = 0.0;
+        double thp[ROM_MAX_NT];
+#pragma unroll
+        for (int t = 0; t < ROM_MAX_NT; ++t) thp[t] = thw[pi[t]];      // four LDS reads in flight together
 #pragma unroll
         for (int t = 0; t < ROM_MAX_NT; ++t) {
           if (t < nt) {
-            const double thp = thw[pi[t]];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) v[b] = fma(thp, raw[t][b], v[b]);
+            for (int b = 0; b < NB; ++b) v[b] = fma(thp[t], raw[t][b], v[b]);
           }
         }
         // raw is dead now: fetch the next k-step into it; the loads fly while this k-step's MFMAs issue
         // (the table is padded by one k-step of zeros, so the last prefetch stays inside it)
         const bool last = ks + 1 == ks1;
-        load_kstep<NB>(p.tv, p.pidx, last ? next_slot : slot0 + (ks + 1 - ks0) * nt, last ? next_nt : nt, p.rp, q, c, raw, pi);
+        load_kstep<NB>(p.tv, p.pidx, last ? next_slot : slot0 + (ks + 1 - ks0) * nt, last ? next_nt : nt, rp_ld, q, c, raw, pi);
         mfma_tiles<NB, NW, W>(v, acc);
       }
     }
