@@ -686,6 +686,78 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
     for (int t = 0; t < nt; ++t) push_slot(tv, pidx, rows4, t);
     nslots += nt;
   }
+  // ---- pattern-uniform k-steps for the single-wave kernels (see RomDev::tvu) ----------------------------------------------
+  std::vector<double> tvu; std::vector<int> kpat, kmeta;
+  d.n_uphases = 0;
+  {
+    struct KStep { std::vector<int> pat; int rows[4]; };
+    std::vector<KStep> ksteps;
+    auto pattern = [&](int row) { return std::vector<int>(a->term_p + a->row_ptr[row], a->term_p + a->row_ptr[row + 1]); };
+    std::vector<int> byp(order);
+    std::stable_sort(byp.begin(), byp.end(), [&](int x, int y) { return pattern(x) < pattern(y); });
+    std::vector<int> left;
+    for (size_t i0 = 0; i0 < byp.size();) {
+      size_t i1 = i0;
+      while (i1 < byp.size() && pattern(byp[i1]) == pattern(byp[i0])) ++i1;
+      size_t i = i0;
+      for (; i + 4 <= i1; i += 4) ksteps.push_back({pattern(byp[i]), {byp[i], byp[i + 1], byp[i + 2], byp[i + 3]}});
+      for (; i < i1; ++i) left.push_back(byp[i]);
+      i0 = i1;
+    }
+    // leftovers: consecutive rows share a k-step as long as the union of their patterns has at most ROM_MAX_NT entries
+    KStep cur{{}, {-1, -1, -1, -1}};
+    int fill = 0;
+    auto flush = [&]() { if (fill) ksteps.push_back(cur); cur = KStep{{}, {-1, -1, -1, -1}}; fill = 0; };
+    for (int row : left) {
+      std::vector<int> u = cur.pat;
+      for (int pp : pattern(row)) if (std::find(u.begin(), u.end(), pp) == u.end()) u.push_back(pp);
+      if (fill == 4 || (int)u.size() > 4) { flush(); u = pattern(row); }
+      cur.pat = u; cur.rows[fill++] = row;
+    }
+    flush();
+    std::stable_sort(ksteps.begin(), ksteps.end(), [](const KStep& x, const KStep& y) { return x.pat.size() > y.pat.size(); });
+    int uslots = 0;
+    for (size_t k = 0; k < ksteps.size(); ++k) {
+      const int nt = (int)ksteps[k].pat.size();
+      if (nt > 4) { delete h; set_error("rom_create: a row of psi has more than 4 terms"); return FINROM_ERR_UNSUPPORTED; }
+      if (d.n_uphases == 0 || d.uphase_nt[d.n_uphases - 1] != nt) {
+        if (d.n_uphases == ROM_MAX_PHASES) { delete h; set_error("rom_create: too many phases"); return FINROM_ERR_UNSUPPORTED; }
+        d.uphase_nt[d.n_uphases] = nt; d.uphase_ks0[d.n_uphases] = (int)k; d.uphase_slot0[d.n_uphases] = uslots;
+        ++d.n_uphases;
+      }
+      d.uphase_ks1[d.n_uphases - 1] = (int)k + 1;
+      for (int t = 0; t < nt; ++t) {
+        const int pp = ksteps[k].pat[t];
+        kpat.push_back(pp);
+        for (int q = 0; q < 4; ++q) {
+          const size_t base = tvu.size();
+          tvu.resize(base + rp, 0.0);
+          const int row = ksteps[k].rows[q];
+          if (row < 0) continue;
+          for (int tt = a->row_ptr[row]; tt < a->row_ptr[row + 1]; ++tt)
+            if (a->term_p[tt] == pp) for (int col = 0; col < r; ++col) tvu[base + col] += a->term_val[(size_t)tt * r + col];
+        }
+      }
+      uslots += nt;
+    }
+    // per-k-step records for the interleaved main loop: {first slot, term count, -, -, theta index of slots 0..3}; four padding
+    // k-steps point at the zero slots behind the table
+    d.nku = (int)ksteps.size();
+    {
+      int sl = 0;
+      for (size_t k = 0; k < ksteps.size(); ++k) {
+        const int nt = (int)ksteps[k].pat.size();
+        int rec[8] = {sl, nt, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < nt; ++t) rec[4 + t] = ksteps[k].pat[t];
+        kmeta.insert(kmeta.end(), rec, rec + 8);
+        sl += nt;
+      }
+      for (int k = 0; k < 4; ++k) { int rec[8] = {uslots, 1, 0, 0, 0, 0, 0, 0}; kmeta.insert(kmeta.end(), rec, rec + 8); }
+    }
+    tvu.resize(tvu.size() + (size_t)4 * 4 * rp, 0.0);       // one k-step of padding for the prefetch
+    kpat.resize(kpat.size() + 16, 0);                        // the scalar pipeline reads up to two k-steps ahead
+    d.tvu_bytes = (int)std::min<size_t>(tvu.size() * sizeof(double), (size_t)0x7FFFFFF0);
+  }
   // chunk images for the LDS-staged kernel: whole k-steps of one phase, <= 32 KiB, padded to 1 KiB
   std::vector<int> ch_nt, ch_nks, ch_off, ch_bytes;
   std::vector<double> tvc;
@@ -753,6 +825,9 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
     if (!rc) rc = up(h->owned, &d.ch_bytes, ch_bytes.data(), ch_bytes.size());
     if (!rc) rc = up(h->owned, &d.tvc, tvc.data(), tvc.size());
   }
+  if (!rc) rc = up(h->owned, &d.tvu, tvu.data(), tvu.size());
+  if (!rc) rc = up(h->owned, &d.kpat, kpat.data(), kpat.size());
+  if (!rc) rc = up(h->owned, &d.kmeta, kmeta.data(), kmeta.size());
   if (!rc) rc = up(h->owned, &d.tv, tv.data(), tv.size());
   if (!rc) rc = up(h->owned, &d.pidx, pidx.data(), pidx.size());
   if (!rc) rc = up(h->owned, &d.rhs_tv, rtv.data(), rtv.size());

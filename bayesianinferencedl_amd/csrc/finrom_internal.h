@@ -155,6 +155,16 @@ struct RomDev {
   int n_chunks;
   const int* ch_nt; const int* ch_nks; const int* ch_off; const int* ch_bytes;   // [n_chunks]; ch_off in doubles
   const double* tvc;                    // chunk images: values then theta indices, each padded to 1 KiB
+  // the same rows regrouped for the single-wave kernels so that the four rows of a k-step share ONE list of theta indices
+  // (rows with the same term pattern together; leftovers merged under the union of their patterns, absent terms = zero
+  // rows): theta then comes from SGPRs, and the k-step needs no theta-index loads, no LDS reads and no per-lane addresses
+  int n_uphases;
+  int uphase_nt[ROM_MAX_PHASES], uphase_ks0[ROM_MAX_PHASES], uphase_ks1[ROM_MAX_PHASES], uphase_slot0[ROM_MAX_PHASES];
+  const double* tvu;                    // [(nuslots + 4) * 4 * rp]
+  const int* kpat;                      // [nuslots + 16] theta index of each slot (0 = the constant 1)
+  int tvu_bytes;
+  int nku;                              // number of pattern-uniform k-steps
+  const int* kmeta;                     // [(nku + 4) * 8] per k-step: first slot, term count, 2 x padding, theta indices of its 4 slots
   const double* tv;                     // [(nslots + 4) * 4 * rp]  padded r-vectors, slot-major
   const int* pidx;                      // [(nslots + 4) * 4]       theta index of each r-vector (0 = constant 1)
   // rows with a non-zero load F (root nodes), same slot format with a runtime term count

@@ -135,8 +135,9 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
 template <int NB, int NW>
 __global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
-                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r) {
-  rom_proj_entry<NB, NW>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r);
+                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
+                                                       const int* __restrict__ kpat) {
+  rom_proj_entry<NB, NW>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -314,7 +315,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
 #define FR_CASE(N, W)                                                                              \
   case N: { constexpr int wpb = W > 4 ? W : 4; constexpr int spb = wpb / W;                        \
             hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + spb - 1) / spb)),     \
-                               dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r); } break;
+                               dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta); } break;
   switch (p.NB) {
     case 1: case 2: case 3: case 4: case 5:      // own translation unit (-O2)
       return launch_rom_proj_single(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, cu_ticket);

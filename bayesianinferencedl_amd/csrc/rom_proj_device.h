@@ -3,10 +3,16 @@
 // is compiled at -O2 (register budget, see _build.py), everything else at -O3.
 #pragma once
 #include "finrom_internal.h"
+#include <type_traits>
 
 namespace finrom {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); sfor<I + 1, N>(f); }
+}
 
 // One k-step = 4 rows of psi.  Rows are sorted by their number of terms, so the k-steps form a
 // few PHASES with a constant term count nt (<= 4): slot t of k-step ks is 4 padded r-vectors at
@@ -70,7 +76,12 @@ __device__ __forceinline__ void mfma_tiles(const double (&v)[NB], d4 (&acc)[(NB 
       if (idx % NW == W) {
         // the wait states for "VALU wrote an operand -> MFMA reads it" sit INSIDE the asm statement: a
         // separate s_nop statement can be scheduled away from the MFMA it is meant to protect
-        if constexpr (kAsm) asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[mine]) : "v"(v[ti]), "v"(v[tj]));
+        // (only the FIRST MFMA of the group can follow the VALU writes of the slab closely; the microbenchmark
+        // tools/mfma_f64_mix.hip shows the pipe taking one MFMA per 64 cycles only when nothing sits between two of them)
+        if constexpr (kAsm) {
+          if (mine == 0) asm volatile("s_nop 7\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[mine]) : "v"(v[ti]), "v"(v[tj]));
+          else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[mine]) : "v"(v[ti]), "v"(v[tj]));
+        }
         else acc[mine] = __builtin_amdgcn_mfma_f64_16x16x4f64(v[ti], v[tj], acc[mine], 0, 0, 0);
         ++mine;
       }
@@ -221,11 +232,121 @@ __device__ __forceinline__ void solve_tiles(const d4 (&acc)[NB * (NB + 1) / 2], 
       }
 }
 
+// ---------------------------------------------------------------------------------------
+// Main loop of the single-wave kernels (NW == 1) on the pattern-uniform tables (RomDev::tvu / kpat).
+// What limits this kernel is not memory (a run whose table fetches all hit one line is as fast) but VECTOR INSTRUCTIONS next
+// to the matrix pipe: tools/mfma_f64_mix.hip -- one v_fma_f64 per v_mfma_f64_16x16x4_f64 costs 17 % of the MFMA rate at two
+// waves per SIMD, an integer VALU op ~6 %, whichever wave issues it; LDS reads are free and loads nearly so.  The loop this
+// one replaces issued 2.4 VALU instructions per MFMA (per-lane theta indices -> LDS addresses, 64-bit table addresses, one
+// multiply-add per table value) and kept the pipe 69 % busy.  Here the four rows of a k-step share their theta indices, so
+//   theta      comes from SGPRs (scalar loads of the sample's parameters, one k-step ahead),
+//   addresses  are buffer loads: table descriptor + SGPR row offset + one constant per-lane offset,
+// and the only vector arithmetic left is NB multiply(-add)s per TERM (1.4 terms per row at the fin): ~0.5 per MFMA.
+// ---------------------------------------------------------------------------------------
+// theta indices / values as wave-uniform values in SGPRs: the tables and the sample's parameters are read through CONSTANT
+// address-space pointers (they are not written during the launch), which is what makes hipcc emit scalar loads and place
+// the waits at the uses; through plain global pointers it never did.
+typedef const int __attribute__((address_space(4)))* c_int_p;
+typedef const double __attribute__((address_space(4)))* c_f64_p;
+typedef int i4 __attribute__((ext_vector_type(4)));
+
+template <int NB> constexpr int tile_ti(int i) { int ti = 0; while (i >= NB - ti) { i -= NB - ti; ++ti; } return ti; }
+template <int NB> constexpr int tile_tj(int i) { int ti = 0; while (i >= NB - ti) { i -= NB - ti; ++ti; } return ti + i; }
+
+// Interleaved form (the default): the burst of non-MFMA work of a k-step does not overlap with the partner wave's MFMAs as
+// one would hope -- tools/mfma_f64_burst.hip: 15 MFMAs + a burst of 7 VALU, 40 SALU and 8 branches reach 75 % of the MFMA rate
+// at two waves per SIMD, whatever the start offset or priority of the second wave -- so it is hidden behind this wave's OWN
+// MFMAs: a 64-cycle MFMA leaves the issuing wave free, and scalar instructions, scalar / buffer loads placed between two MFMAs
+// cost the pipe (almost) nothing (tools/mfma_f64_mix.hip).  One k-step = the MFMAs on slab vc, and in the gaps:
+//   gap 0      the next slab vn = sum_t theta_t raw_t             (all vector arithmetic in ONE gap: the first VALU
+//              instruction behind an MFMA costs ~15 cycles of pipe time, each further one ~4)
+//   gaps 1..4  raw_t <- table rows of the k-step after next        (buffer loads; one k-step to land)
+//   gap 5      scalar loads: thetas + record of the k-steps ahead  (constant address space; consumed in the next iteration)
+// Two slab buffers, loop unrolled twice; per-k-step records (RomDev::kmeta) make every address a function of the loop
+// counter.  Term counts are run-time, wave-uniform: scalar branches between the MFMAs.
+template <int NB>
+__device__ __forceinline__ void proj_main_uniform(const RomDev& p, const int* __restrict__ kmeta_g,
+                                                  const double* __restrict__ theta_g, int q, int c,
+                                                  d4 (&acc)[NB * (NB + 1) / 2]) {
+  constexpr int NTL = NB * (NB + 1) / 2;
+  typedef const i4 __attribute__((address_space(4)))* c_i4_p;
+  const c_i4_p kmeta = (c_i4_p)(unsigned long long)kmeta_g;             // record ks = kmeta[2 ks] (slot, nt, -, -), kmeta[2 ks + 1] (theta indices)
+  const c_f64_p theta_s = (c_f64_p)(unsigned long long)theta_g;
+  const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.tvu), 0, p.tvu_bytes, 0x00020000);
+  const int voff = (q * p.rp + c) * 8;
+  const int rowb = 4 * p.rp * 8;                         // bytes per slot (4 rows)
+  auto ldt = [&](int slot, auto bc) -> double {
+    constexpr int b = decltype(bc)::value;
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * b, slot * rowb, 0));
+  };
+  auto theta_of = [&](int pp) -> double { return pp == 0 ? 1.0 : theta_s[pp - 1]; };     // index 0 = the constant 1
+  auto load_raw = [&](double (&raw)[ROM_MAX_NT][NB], auto tc, int slot, int nt) {
+    constexpr int t = decltype(tc)::value;
+    if (t < nt) {
+      asm volatile("" ::: "memory");                     // (keeps the branch a branch)
+      sfor<0, NB>([&](auto bc) { raw[t][decltype(bc)::value] = ldt(slot + t, bc); });
+    }
+  };
+  auto build = [&](double (&v)[NB], const double (&raw)[ROM_MAX_NT][NB], const double (&th)[ROM_MAX_NT], int nt) {
+    sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; v[b] = th[0] * raw[0][b]; });
+    sfor<1, ROM_MAX_NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if (t < nt) {
+        asm volatile("" ::: "memory");
+        sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; v[b] = fma(th[t], raw[t][b], v[b]); });
+      }
+    });
+  };
+  double raw[ROM_MAX_NT][NB], th1[ROM_MAX_NT], va[NB], vb[NB];
+  sfor<0, ROM_MAX_NT>([&](auto tc) { sfor<0, NB>([&](auto bc) { raw[decltype(tc)::value][decltype(bc)::value] = 0.0; }); });
+  // prologue: slab of k-step 0, raw <- k-step 1, scalars of k-steps 1 and 2
+  i4 m0 = kmeta[0], k0 = kmeta[1];
+  sfor<0, ROM_MAX_NT>([&](auto tc) { load_raw(raw, tc, m0[0], m0[1]); });
+  sfor<0, ROM_MAX_NT>([&](auto tc) { th1[decltype(tc)::value] = theta_of(k0[decltype(tc)::value]); });
+  build(va, raw, th1, m0[1]);
+  i4 m1 = kmeta[2], k1 = kmeta[3];
+  sfor<0, ROM_MAX_NT>([&](auto tc) { load_raw(raw, tc, m1[0], m1[1]); });
+  sfor<0, ROM_MAX_NT>([&](auto tc) { th1[decltype(tc)::value] = theta_of(k1[decltype(tc)::value]); });
+  int nt1 = m1[1];
+  i4 m2 = kmeta[4], k2 = kmeta[5];
+  asm volatile("s_nop 7" ::: "memory");                  // va was written by VALU just now: VALU -> MFMA operand wait states
+
+  auto step = [&](double (&vc)[NB], double (&vn)[NB], int ks) {
+    double th2[ROM_MAX_NT];
+    i4 m3, k3;
+    sfor<0, NTL>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int ti = tile_ti<NB>(i), tj = tile_tj<NB>(i);
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(vc[ti]), "v"(vc[tj]));
+      constexpr int last = NTL - 1;
+      if constexpr (i == 0) build(vn, raw, th1, nt1);
+      if constexpr (i == (1 < last ? 1 : last)) load_raw(raw, std::integral_constant<int, 0>{}, m2[0], m2[1]);
+      if constexpr (i == (2 < last ? 2 : last)) load_raw(raw, std::integral_constant<int, 1>{}, m2[0], m2[1]);
+      if constexpr (i == (3 < last ? 3 : last)) load_raw(raw, std::integral_constant<int, 2>{}, m2[0], m2[1]);
+      if constexpr (i == (4 < last ? 4 : last)) load_raw(raw, std::integral_constant<int, 3>{}, m2[0], m2[1]);
+      if constexpr (i == (5 < last ? 5 : last)) {
+        sfor<0, ROM_MAX_NT>([&](auto tc) { th2[decltype(tc)::value] = theta_of(k2[decltype(tc)::value]); });
+        m3 = kmeta[2 * (ks + 3)]; k3 = kmeta[2 * (ks + 3) + 1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, ROM_MAX_NT>([&](auto tc) { th1[decltype(tc)::value] = th2[decltype(tc)::value]; });
+    nt1 = m2[1]; m2 = m3; k2 = k3;
+  };
+  const int nku = p.nku;
+#pragma unroll 1
+  for (int ks = 0; ks < nku; ks += 2) {
+    step(va, vb, ks);
+    if (ks + 1 < nku) step(vb, va, ks + 1);
+  }
+}
+
 template <int NB, int NW, int W>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                               int* __restrict__ info, double* __restrict__ w_r = nullptr,
-                                              double* __restrict__ qoi_r = nullptr, double* slab = nullptr) {
+                                              double* __restrict__ qoi_r = nullptr, double* slab = nullptr,
+                                              const double* __restrict__ theta_s = nullptr, const int* __restrict__ kpat = nullptr) {
   constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
   const int q = lane >> 4, c = lane & 15;
   d4 acc[NTL];
@@ -280,6 +401,8 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
         mfma_tiles<NB, NW, W>(v, acc);
       }
     }
+  } else if ((p.clock_probe & 15) != 3) {      // (bits 4 / 5: timing experiments without table loads / without scalar loads)
+    proj_main_uniform<NB>(p, kpat, theta_s, q, c, acc);      // kpat = RomDev::kmeta as a kernel parameter  // (FINROM_CLOCK_PROBE=3: the per-lane-theta loop below, for A/B timing)
   } else
   // ONE copy of the MFMA group for all phases (runtime term count): several unrolled copies make hipcc
   // spill the inline-asm accumulators around every copy
@@ -417,7 +540,8 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 template <int NB, int NW>
 __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
-                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r) {
+                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
+                                                       const int* __restrict__ kpat = nullptr) {
   constexpr int WPB = NW > 4 ? NW : 4;
   static_assert(NW == 1 || NW >= 4, "a workgroup is one sample when its waves share the slab (uniform early exit, barriers)");
   __shared__ double th[WPB][32];
@@ -427,12 +551,17 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
   trace_begin(p.trace, blockIdx.x);
   const int64_t s = (int64_t)blockIdx.x * (WPB / NW) + wave / NW;
   if (s >= S) return;                       // no block-wide barrier below
-  if (lane == 0) th[wave][0] = 1.0;
+  if (lane == 0) { th[wave][0] = 1.0; th[wave][p.P + 1] = 0.0; }    // theta index P + 1 = the zero of padded table slots
   if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
   __builtin_amdgcn_wave_barrier();
   const double* thw = th[wave];
   if constexpr (NW == 1) {
-    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r);
+    // the sample index is wave-uniform: say so, so that the sample's parameters can be fetched with scalar loads
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned long long ta = (unsigned long long)(theta + ((int64_t)blockIdx.x * (WPB / NW) + wave_u) * p.P);
+    const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));     // provably in SGPRs
+    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r, nullptr, theta_s, kpat);
   } else if constexpr (NW == 2) {
     if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab);
     else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab);

@@ -10,15 +10,16 @@ template <int NB>
 __global__ __launch_bounds__(256, 2) void rom_proj_single_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                                  double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                                  int* __restrict__ info, double* __restrict__ w_r,
-                                                                 double* __restrict__ qoi_r) {
-  rom_proj_entry<NB, 1>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r);
+                                                                 double* __restrict__ qoi_r, const int* __restrict__ kpat) {
+  // (kpat = p.kpat as a __restrict__ kernel parameter of its own: only then are its reads scalar loads)
+  rom_proj_entry<NB, 1>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
 }
 
 int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                            hipStream_t st, double* w_r, double* qoi_r, int* /*cu_ticket: unused (stagger experiment)*/) {
   const dim3 grid((unsigned)((S + 3) / 4)), block(256);
   switch (p.NB) {
-#define FR_ONE(N) case N: hipLaunchKernelGGL(rom_proj_single_kernel<N>, grid, block, 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r); break;
+#define FR_ONE(N) case N: hipLaunchKernelGGL(rom_proj_single_kernel<N>, grid, block, 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta); break;
     FR_ONE(1) FR_ONE(2) FR_ONE(3) FR_ONE(4) FR_ONE(5)
 #undef FR_ONE
     default: set_error("rom_proj_single: basis size > 80"); return FINROM_ERR_UNSUPPORTED;
