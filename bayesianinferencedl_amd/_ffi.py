@@ -99,6 +99,7 @@ SIGNATURES = {
     "finrom_sampler_create": (C.c_int, [c_f64p, C.c_int32, C.POINTER(C.c_void_p)]),
     "finrom_sampler_destroy": (None, [C.c_void_p]),
     "finrom_sampler_draw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "finrom_sampler_draw_seeded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "finrom_solve_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 8),
     "finrom_sub": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }

@@ -70,6 +70,7 @@ static void drain_pending() {
 int launch_subfin_avg(const double*, int, int, const double*, int64_t, double*, hipStream_t);
 int launch_sampler(const double*, int, const double*, int64_t, double*, hipStream_t);
 int launch_sub(const double*, const double*, int64_t, double*, hipStream_t);
+int launch_philox_normal(unsigned long long, int64_t, int64_t, int, double*, hipStream_t);
 
 }  // namespace finrom
 
@@ -93,7 +94,7 @@ struct finrom_rom_s {
   hipStream_t side = nullptr;          // library-owned stream for the ROM half of finrom_solve_pairs
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
-struct finrom_sampler_s { double* U = nullptr; int n = 0; };
+struct finrom_sampler_s { double* U = nullptr; int n = 0; Scratch xi; };
 
 template <class T>
 static int up(std::vector<void*>& owned, const T** dst, const T* host, size_t count) {
@@ -1038,12 +1039,11 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     if ((rc = rom->theta.reserve((size_t)S * rom->d.P * sizeof(double)))) return rc;
     theta = (double*)rom->theta.p;
   }
-  // the two halves run on two streams (FINROM_NO_OVERLAP / finrom_set_overlap(0): in turn, for per-kernel profiling)
-  // With the band sweep as the FOM half there is nothing to gain from running the halves side by side: it is HBM-bound at one
-  // 300-register wave per SIMD and evicts the projection's second wave (measured: 36.2 ms overlapped vs 31.9 ms in turn per
-  // 100k samples); the interpreter (latency-bound, 56 registers) does overlap.  FINROM_FORCE_OVERLAP=1 overrides.
-  const bool band_fom = fom->band.on && getenv("FINROM_NO_BAND") == nullptr && !(fom->small.small_max > 0 && S <= fom->small.small_max);
-  const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr && (!band_fom || getenv("FINROM_FORCE_OVERLAP") != nullptr);
+  // The two halves run on two streams (FINROM_NO_OVERLAP / finrom_set_overlap(0): in turn, for per-kernel profiling).  With the
+  // band sweep as the FOM half (HBM-bound, one 300-register wave per SIMD, vector units 80 % idle) a projection wave fits beside
+  // every sweep wave, and since the projection hides its non-MFMA work behind its own MFMAs a lone wave per SIMD is efficient:
+  // measured 26.3 ms side by side against 29.1 ms in turn per 100k samples (r = 80).
+  const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr;
   hipStream_t side = overlap ? rom->side : st;
   const bool tracing = trace_prefix() != nullptr;
   if (tracing) {
@@ -1088,6 +1088,11 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
 
 int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out) {
   if (!U || n <= 0 || !out) { set_error("sampler_create: bad argument"); return FINROM_ERR_ARG; }
+  // the kernel only visits the K-range of an UPPER factor (scipy.linalg.cholesky's default, gaussian_field.py:30): a lower
+  // factor such as np.linalg.cholesky(C) would silently give wrong fields
+  for (int i = 1; i < n; ++i)
+    for (int j = 0; j < i; ++j)
+      if (U[(size_t)i * n + j] != 0.0) { set_error("sampler_create: U must be upper triangular (pass the transpose of a lower factor)"); return FINROM_ERR_ARG; }
   auto* h = new finrom_sampler_s();
   h->n = n;
   int rc = upload(&h->U, U, (size_t)n * n);
@@ -1095,10 +1100,27 @@ int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out) {
   *out = h;
   return 0;
 }
-void finrom_sampler_destroy(finrom_sampler_t h) { if (!h) return; if (h->U) (void)hipFree(h->U); delete h; }
+void finrom_sampler_destroy(finrom_sampler_t h) { if (!h) return; if (h->U) (void)hipFree(h->U); h->xi.release(); delete h; }
 int finrom_sampler_draw(finrom_sampler_t h, const double* xi, int64_t S, double* k, void* stream) {
   if (!h || S < 0 || (S > 0 && (!xi || !k))) { set_error("sampler_draw: bad argument"); return FINROM_ERR_ARG; }
   return launch_sampler(h->U, h->n, xi, S, k, (hipStream_t)stream);
+}
+
+int finrom_sampler_draw_seeded(finrom_sampler_t h, uint64_t seed, int64_t first_global_sample, int64_t S, double* k, double* xi_out,
+                               void* stream) {
+  if (!h || S < 0 || first_global_sample < 0 || (S > 0 && !k)) { set_error("sampler_draw_seeded: bad argument"); return FINROM_ERR_ARG; }
+  hipStream_t st = (hipStream_t)stream;
+  // pieces of <= 32k samples bound the xi scratch (1 GiB at n = 4101) when the caller does not want xi back
+  const int64_t piece = xi_out ? S : std::min<int64_t>(S, 32768);
+  for (int64_t s0 = 0; s0 < S; s0 += piece) {
+    const int64_t Sc = std::min(piece, S - s0);
+    double* xi = xi_out ? xi_out + s0 * h->n : nullptr;
+    if (!xi) { int rc = h->xi.reserve((size_t)Sc * h->n * sizeof(double)); if (rc) return rc; xi = (double*)h->xi.p; }
+    int rc = launch_philox_normal(seed, first_global_sample + s0, Sc, h->n, xi, st);
+    if (!rc) rc = launch_sampler(h->U, h->n, xi, Sc, k + s0 * h->n, st);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {

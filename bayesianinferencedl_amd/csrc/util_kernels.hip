@@ -1,5 +1,6 @@
 // Small helper kernels of the hot path: sub-fin averages, Gaussian-field sampler, difference.
 #include "finrom_internal.h"
+#include <algorithm>
 
 namespace finrom {
 
@@ -97,6 +98,54 @@ int launch_sampler(const double* U, int n, const double* xi, int64_t S, double* 
   ScopedKernelTimer t(K_SAMPLER, st);
   dim3 grid((unsigned)((S + 63) / 64), (unsigned)((n + 63) / 64));
   hipLaunchKernelGGL(sampler_kernel, grid, dim3(256), 0, st, U, n, xi, S, k);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// xi ~ N(0, I) on the device, keyed by the GLOBAL sample index (deep_learning/generate_fin_dataset.py:87 draws them with
+// np.random.randn): Philox4x32-10, counter = (sample index lo, hi, pair index, 0), key = seed; the four output words make
+// two 53-bit uniforms and Box-Muller turns them into the pair xi[2 jb], xi[2 jb + 1].  A sample's draw depends on nothing but
+// (seed, its global index): any sharding of a dataset over GPUs produces the same fields.
+// oracle/fin_oracle.py::philox_normal is the NumPy restatement the tests compare with.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__global__ __launch_bounds__(256) void philox_normal_kernel(unsigned long long seed, int64_t first, int64_t S, int n,
+                                                            double* __restrict__ xi) {
+  const int npair = (n + 1) / 2;
+  const int64_t total = S * npair;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t sl = i / npair;
+    const int jb = (int)(i - sl * npair);
+    const unsigned long long g = (unsigned long long)(first + sl);
+    unsigned o[4];
+    philox4x32_10((unsigned)g, (unsigned)(g >> 32), (unsigned)jb, 0u, (unsigned)seed, (unsigned)(seed >> 32), o);
+    const unsigned long long a = ((unsigned long long)o[1] << 32) | o[0], b = ((unsigned long long)o[3] << 32) | o[2];
+    const double u1 = (double)((a >> 11) + 1) * 0x1.0p-53;       // (0, 1]
+    const double u2 = (double)(b >> 11) * 0x1.0p-53;             // [0, 1)
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586476925286766559 * u2;
+    xi[sl * n + 2 * jb] = rad * cos(ang);
+    if (2 * jb + 1 < n) xi[sl * n + 2 * jb + 1] = rad * sin(ang);
+  }
+}
+
+int launch_philox_normal(unsigned long long seed, int64_t first, int64_t S, int n, double* xi, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_MISC, st);
+  const int64_t total = S * ((n + 1) / 2);
+  const int64_t blocks = std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, st, seed, first, S, n, xi);
   FR_HIP(hipGetLastError());
   return 0;
 }

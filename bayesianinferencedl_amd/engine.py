@@ -373,6 +373,17 @@ class FieldSampler:
         check(lib().finrom_sampler_draw(self._h, b.ptr, b.S, kp, b.stream), "finrom_sampler_draw")
         return b.out(k, (b.S, self.n))
 
+    def draw(self, seed, first, S, like=None, want_xi=False):
+        """S fields of the stream `seed` starting at GLOBAL sample index `first`, xi drawn on the device (Philox keyed by the
+        global index: independent of how a dataset is sharded).  like: a torch CUDA tensor (-> torch outputs on its device /
+        current stream) or None (-> NumPy).  Returns k [S, n] (and xi [S, n] if want_xi)."""
+        b = _Batch(like if like is not None else np.zeros((0, self.n)), self.n)
+        k, kp = b.new((S, self.n))
+        xi, xp = b.new((S, self.n)) if want_xi else (None, None)
+        check(lib().finrom_sampler_draw_seeded(self._h, int(seed), int(first), int(S), kp, xp, b.stream), "finrom_sampler_draw_seeded")
+        out = b.out(k, (S, self.n))
+        return (out, b.out(xi, (S, self.n))) if want_xi else out
+
     def close(self):
         if getattr(self, "_h", None):
             lib().finrom_sampler_destroy(self._h)

@@ -279,10 +279,15 @@ int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n,
 /* ---- Gaussian-field sampler  k = exp(0.5 * U^T xi) ----------------------------------- *
  * (deep_learning/generate_fin_dataset.py:87-88 with U = make_cov_chol(...),
  *  bayesian_inference/gaussian_field.py:9-31; U is the UPPER factor, row-major [n x n],
- *  host pointer copied at create).  xi [S x n] -> k [S x n]. */
+ *  host pointer copied at create; anything below the diagonal is an error).  xi [S x n] -> k [S x n]. */
 int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out);
 void finrom_sampler_destroy(finrom_sampler_t h);
 int finrom_sampler_draw(finrom_sampler_t h, const double* xi, int64_t S, double* k, void* stream);
+/* The same with xi drawn ON THE DEVICE (the reference draws np.random.randn per sample, generate_fin_dataset.py:87):
+ * Philox4x32-10, counter = (global sample index, pair index), key = seed, Box-Muller; sample first_global_sample + s of
+ * the stream `seed` is the same numbers whatever shard or GPU draws it.  k [S x n]; xi_out [S x n] or NULL. */
+int finrom_sampler_draw_seeded(finrom_sampler_t h, uint64_t seed, int64_t first_global_sample, int64_t S, double* k,
+                               double* xi_out, void* stream);
 
 /* ---- the dataset-loop body for S samples in one call ---------------------------------- *
  * (deep_learning/generate_fin_dataset.py:93-100):  FOM solve + QoI on the caller's stream;

@@ -501,6 +501,38 @@ def sample_fields(chol, xi):
     return np.exp(0.5 * (xi @ chol))
 
 
+def philox4x32_10(c, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123): c = four uint64 arrays holding 32-bit counter words, (k0, k1) the key.
+    Pinned by Random123's known-answer vectors in tests/test_oracle.py."""
+    M = np.uint64(0xFFFFFFFF)
+    c = [np.asarray(w, np.uint64) for w in c]
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]; p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & M, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & M]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & M; k1 = (k1 + np.uint64(0xBB67AE85)) & M
+    return c
+
+
+def philox_normal(seed, first, S, n):
+    """NumPy restatement of the library's device draw (csrc/util_kernels.hip::philox_normal_kernel): Philox4x32-10 with
+    counter (global sample index lo, hi, pair index, 0) and key (seed lo, hi); words (o0, o1) and (o2, o3) give two 53-bit
+    uniforms u1 in (0, 1], u2 in [0, 1); Box-Muller pair -> xi[s, 2 jb], xi[s, 2 jb + 1].  The reference draws
+    np.random.randn (deep_learning/generate_fin_dataset.py:87); this is the seeded, shard-independent stand-in."""
+    npair = (n + 1) // 2
+    g = (np.arange(S, dtype=np.uint64) + np.uint64(first))[:, None] + np.zeros((1, npair), np.uint64)
+    c = philox4x32_10([g & np.uint64(0xFFFFFFFF), g >> np.uint64(32),
+                       np.broadcast_to(np.arange(npair, dtype=np.uint64), g.shape).copy(), np.zeros_like(g)],
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    a = (c[1] << np.uint64(32)) | c[0]; b = (c[3] << np.uint64(32)) | c[2]
+    u1 = ((a >> np.uint64(11)) + np.uint64(1)).astype(np.float64) * 2.0 ** -53
+    u2 = (b >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    rad = np.sqrt(-2.0 * np.log(u1)); ang = 6.283185307179586476925286766559 * u2
+    xi = np.empty((S, 2 * npair))
+    xi[:, 0::2] = rad * np.cos(ang); xi[:, 1::2] = rad * np.sin(ang)
+    return xi[:, :n]
+
+
 def pod_basis(snapshots, r):
     """Orthonormal POD basis of the snapshot rows [num, n] -> [n, r] (SVD; the reference's
     recipe at rom/generate_reduced_basis_nine_param.py:296-318 leaves modes unnormalised,

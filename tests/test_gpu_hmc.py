@@ -51,8 +51,8 @@ def test_hmc_chains_value_and_gradient_match_the_oracle(setup, projection):
     for ev, K, loss, grad in res.recorded:
         for c in range(len(chains)):
             go, lo = O.grad_romml_oracle(ro, model, K[c])
-            # value: fp64 ROM + fp32 network output entering a residual of order 0.1 -> 1e-6 relative on the loss
-            assert abs(loss[c] - lo) <= 1e-6 * abs(lo), (ev, c, loss[c], lo)
+            # value: fp64 ROM + fp32 network output (1e-7 absolute) entering a residual of order 0.1: ~5e-6 relative on the loss
+            assert abs(loss[c] - lo) <= 2e-5 * abs(lo), (ev, c, loss[c], lo)
             assert np.linalg.norm(grad[c] - go) <= 1e-5 * np.linalg.norm(go), (ev, c)
     # a chain alone walks the same path as the same chain advanced in lockstep with others (fp32 network: GEMV vs GEMM order)
     solo = hmc.run_chains(hmc.romml_value_and_grad(rom), K0[1:2], 21, seeds=[7])
