@@ -225,12 +225,9 @@ def main():
         from bayesianinferencedl_amd.bayesian_inference.gaussian_field import make_cov_chol
         from bayesianinferencedl_amd.engine import FieldSampler
         sampler = FieldSampler(make_cov_chol(V, length=1.6))
-        X = torch.empty((S, V.dim()), dtype=torch.float64, device=dev)
-        for s0 in range(0, S, 16384):                      # xi in pieces: bounded host memory at the 125k-sample shard
-            s1 = min(S, s0 + 16384)
-            xi = torch.from_numpy(global_normal(5, rank * S + s0, rank * S + s1, V.dim())).to(dev)
-            X[s0:s1] = sampler(xi)
-        del xi
+        # xi on the device: Philox keyed by the GLOBAL sample index (seed 5), so rank g's shard is rows [g S, (g + 1) S) of one
+        # stream whatever the GPU count -- no host draw, no upload (finrom_sampler_draw_seeded)
+        X = sampler.draw(5, rank * S, S, like=torch.empty(0, device=dev, dtype=torch.float64))
     else:
         X = torch.from_numpy(global_uniform(3, rank * S, (rank + 1) * S, pairs.xdim)).to(dev)
     from bayesianinferencedl_amd.distributed import gather_rows

@@ -504,3 +504,22 @@ def test_sq_error_ops_value_and_gradient(problems, spaces):
         assert abs(float(out[0][0]) - want[0]) < 1e-8 * abs(want[0])
         assert np.linalg.norm(out[1][0] - want[1]) < 1e-6 * np.linalg.norm(want[1])
         assert np.allclose(op.grad([k], [2.0])[0], 2.0 * out[1][0])
+
+
+def test_device_philox_sampler_matches_the_oracle_and_ignores_the_shard_cut(problems, spaces):
+    """finrom_sampler_draw_seeded: xi drawn on the device (Philox4x32-10 keyed by the global sample index) against the oracle's
+    NumPy restatement (pinned by Random123's known-answer vectors), the fields k = exp(0.5 U^T xi) against the oracle's, and
+    bit-identical rows for any cut of the sample range."""
+    from bayesianinferencedl_amd.bayesian_inference.gaussian_field import make_cov_chol
+    from bayesianinferencedl_amd.engine import FieldSampler
+    m = 4
+    prob, V = problems(m), spaces(m)
+    chol = make_cov_chol(V, length=1.6)
+    smp = FieldSampler(chol)
+    k, xi = smp.draw(5, 1000, 300, want_xi=True)
+    ref_xi = O.philox_normal(5, 1000, 300, prob.n)
+    assert np.max(np.abs(xi - ref_xi)) < 1e-13
+    assert rel(k, O.sample_fields(chol, ref_xi)) < 1e-12
+    a, b = smp.draw(5, 1000, 111), smp.draw(5, 1111, 189)
+    assert np.array_equal(np.concatenate([a, b]), k)
+    assert not np.array_equal(smp.draw(6, 1000, 4), k[:4])

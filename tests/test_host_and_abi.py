@@ -278,3 +278,14 @@ def test_band_plan_replay_solves_the_fom(spaces, m):
         assert np.linalg.norm(sol - ref) < 1e-12 * np.linalg.norm(ref)
     with pytest.raises(np.linalg.LinAlgError):
         bp.replay(-AB, ops.F)
+
+
+def test_sampler_rejects_a_lower_triangular_factor():
+    """finrom_sampler_create only accepts the UPPER factor scipy.linalg.cholesky returns (gaussian_field.py:30); a lower factor
+    (np.linalg.cholesky) would silently give wrong fields, so it is an argument error (checked before any device call)."""
+    import ctypes as C
+    from bayesianinferencedl_amd import _ffi
+    L = np.linalg.cholesky(np.eye(5) + 0.1 * np.ones((5, 5)))
+    h = C.c_void_p()
+    rc = _ffi.lib().finrom_sampler_create(np.ascontiguousarray(L).ctypes.data_as(_ffi.c_f64p), 5, C.byref(h))
+    assert rc == -1 and b"upper" in _ffi.lib().finrom_last_error()

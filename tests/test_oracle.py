@@ -200,3 +200,21 @@ def test_enrich_matches_reference_module():
     basis = np.linalg.qr(rng.standard_normal((50, 6)))[0]
     w = rng.standard_normal((50, 1))
     assert np.allclose(mod.enrich(basis.copy(), w.copy()), enrich(basis, w), rtol=1e-13, atol=1e-15)
+
+
+def test_philox_core_matches_random123_known_answers():
+    """oracle.philox4x32_10 against the known-answer vectors shipped with Random123 (kat_vectors, philox4x32 10 rounds)."""
+    for ctr, key, want in (([0, 0, 0, 0], [0, 0], "6627e8d5 e169c58d bc57ac4c 9b00dbd8"),
+                           ([0xffffffff] * 4, [0xffffffff] * 2, "408f276d 41c83b0e a20bc7c6 6d5451fd"),
+                           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+                            "d16cfe09 94fdcceb 5001e420 24126ea1")):
+        out = O.philox4x32_10([np.array([w], np.uint64) for w in ctr], key[0], key[1])
+        assert " ".join("%08x" % int(w[0]) for w in out) == want
+
+
+def test_philox_normals_are_keyed_by_the_global_sample_index():
+    xi = O.philox_normal(5, 0, 3000, 245)
+    assert xi.shape == (3000, 245) and abs(xi.mean()) < 5e-3 and abs(xi.std() - 1) < 5e-3 and np.isfinite(xi).all()
+    assert np.array_equal(O.philox_normal(5, 1200, 50, 245), xi[1200:1250])            # any shard cut gives the same rows
+    assert not np.array_equal(O.philox_normal(6, 0, 10, 245), xi[:10])
+    assert np.array_equal(O.philox_normal(5, 2 ** 33 + 7, 2, 9)[1], O.philox_normal(5, 2 ** 33 + 8, 1, 9)[0])   # 64-bit index
