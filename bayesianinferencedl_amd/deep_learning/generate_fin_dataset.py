@@ -22,8 +22,23 @@ from ..rom.basis import load_or_build_basis
 log = logging.getLogger(__name__)
 
 
+def _tags(dataset_size):
+    """File-name tags of the reference (:102-110): > 1000 samples -> training set, < 600 -> evaluation set (both: neither)."""
+    return (["tr"] if dataset_size > 1000 else []) + (["eval"] if dataset_size < 600 else [])
+
+
 def gen_affine_avg_rom_dataset(dataset_size, resolution=40, genrand=False, *, phi=None, seed=None,
-                               out_dir='../data', basis_path='../data/basis_nine_param.txt', batch=65536):
+                               out_dir='../data', basis_path='../data/basis_nine_param.txt', batch=65536,
+                               device_rng=False, _stop_after_batches=None):
+    """Returns (z_s [S, n], qoi_errors [S, n_obs]) like the reference and writes the three .npy files with its names.
+
+    Host memory is bounded by one batch: when the files are written (out_dir exists and the size selects a file set) the
+    outputs are memory-mapped .npy files filled shard by shard (one shard = `batch` samples, flushed as it completes), and the
+    returned arrays are those maps -- 1 M samples x 4101 dofs is 33 GB of z_s that never sits in RAM.  With a `seed` the run is
+    resumable: a side file records the completed shards and a rerun with the same arguments continues after the last one (the
+    random stream is advanced past them).  device_rng=True draws xi on the device (Philox keyed by the global sample index,
+    needs a seed) instead of np.random.RandomState(seed).randn per shard (:87)."""
+    import json
     V = get_space(resolution)
     solver = Fin(V, genrand)                                           # :66
     if phi is None:
@@ -32,29 +47,58 @@ def gen_affine_avg_rom_dataset(dataset_size, resolution=40, genrand=False, *, ph
     solver_r = AffineROMFin(V, None, phi, genrand)                     # :76 (err_model unused by the forward path)
     pairs = FinPairSolver(V, phi, genrand, "field", solver, solver_r)
     sampler = FieldSampler(chol)
+    if device_rng and seed is None:
+        raise ValueError("device_rng needs a seed (the device stream is keyed by (seed, global sample index))")
 
-    qoi_errors = np.zeros((dataset_size, solver_r.n_obs))
-    qois = np.zeros((dataset_size, solver_r.n_obs))
-    z_s = np.zeros((dataset_size, V.dim()))
+    n, n_obs = V.dim(), solver_r.n_obs
+    tags = _tags(dataset_size) if out_dir is not None and os.path.isdir(out_dir) else []
+    if out_dir is not None and not os.path.isdir(out_dir):
+        log.warning("output directory %s does not exist; dataset not saved", out_dir)
+    done, prog_path, meta = 0, None, None
+    if tags:
+        first = tags[0]
+        names = {"z": f"z_aff_avg_{first}_avg_obs_3.npy", "err": f"errors_aff_avg_{first}_avg_obs_3.npy", "qoi": f"qois_avg_{first}_avg_obs_3.npy"}
+        paths = {k: os.path.join(out_dir, v) for k, v in names.items()}
+        shapes = {"z": (dataset_size, n), "err": (dataset_size, n_obs), "qoi": (dataset_size, n_obs)}
+        meta = {"dataset_size": int(dataset_size), "seed": seed, "batch": int(batch), "n": int(n), "n_obs": int(n_obs),
+                "device_rng": bool(device_rng)}
+        prog_path = os.path.join(out_dir, f".gen_affine_avg_rom_dataset_{first}.progress.json")
+        if seed is not None and os.path.exists(prog_path) and all(os.path.exists(p_) for p_ in paths.values()):
+            with open(prog_path) as f:
+                prev = json.load(f)
+            if {k: prev.get(k) for k in meta} == meta:
+                done = int(prev.get("done", 0))
+        mode = "r+" if done else "w+"
+        arr = {k: np.lib.format.open_memmap(paths[k], mode=mode, dtype=np.float64, shape=None if done else shapes[k]) for k in paths}
+        z_s, qoi_errors, qois = arr["z"], arr["err"], arr["qoi"]
+    else:
+        qoi_errors = np.zeros((dataset_size, n_obs))
+        qois = np.zeros((dataset_size, n_obs))
+        z_s = np.zeros((dataset_size, n))
     rng = np.random.RandomState(seed)      # the reference uses the unseeded global state (:87)
-    for s0 in range(0, dataset_size, batch):
+    for ib, s0 in enumerate(range(0, dataset_size, batch)):
         s1 = min(dataset_size, s0 + batch)
-        norm = rng.randn(s1 - s0, V.dim())                             # :87
-        nodal_vals = sampler(norm)                                     # :88  exp(0.5 * chol.T @ norm)
+        if ib < done:
+            if not device_rng:
+                rng.randn(s1 - s0, n)                                  # advance the stream past a completed shard
+            continue
+        if _stop_after_batches is not None and ib >= _stop_after_batches:
+            break                                                      # (tests: an interrupted run)
+        if device_rng:
+            nodal_vals = sampler.draw(seed, s0, s1 - s0)               # :87-88 on the device
+        else:
+            norm = rng.randn(s1 - s0, n)                               # :87
+            nodal_vals = sampler(norm)                                 # :88  exp(0.5 * chol.T @ norm)
         res = pairs.solve_pairs(nodal_vals)                            # :93-97
         z_s[s0:s1] = nodal_vals
         qoi_errors[s0:s1] = res["err"]                                 # :99
         qois[s0:s1] = res["qoi"]                                       # :100
-
-    if out_dir is not None and os.path.isdir(out_dir):                 # :102-110
-        if dataset_size > 1000:
-            np.save(os.path.join(out_dir, 'z_aff_avg_tr_avg_obs_3'), z_s)
-            np.save(os.path.join(out_dir, 'errors_aff_avg_tr_avg_obs_3'), qoi_errors)
-            np.save(os.path.join(out_dir, 'qois_avg_tr_avg_obs_3'), qois)
-        if dataset_size < 600:
-            np.save(os.path.join(out_dir, 'z_aff_avg_eval_avg_obs_3'), z_s)
-            np.save(os.path.join(out_dir, 'errors_aff_avg_eval_avg_obs_3'), qoi_errors)
-            np.save(os.path.join(out_dir, 'qois_avg_eval_avg_obs_3'), qois)
-    elif out_dir is not None:
-        log.warning("output directory %s does not exist; dataset not saved", out_dir)
+        if tags:
+            for a_ in (z_s, qoi_errors, qois):
+                a_.flush()
+            if seed is not None:
+                with open(prog_path, "w") as f:
+                    json.dump(dict(meta, done=ib + 1), f)
+    if tags and prog_path and os.path.exists(prog_path) and (_stop_after_batches is None):
+        os.remove(prog_path)
     return (z_s, qoi_errors)
