@@ -62,3 +62,39 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+
+
+def build_asan() -> str:
+    """Host-side AddressSanitizer + UBSan build of the C-ABI layer (csrc/finrom_api.hip: the create-time validators of every
+    descriptor) for the CPU box: only the HOST code of finrom_api.hip is instrumented (-Xarch_host), the kernels' objects are
+    the product's.  GPU sanitizers are not available on this pool; tools/asan_validators.py drives the corrupt-descriptor
+    cases through this library without a GPU (a corrupt descriptor is rejected before any device call)."""
+    build()
+    hipcc = _hipcc()
+    obj = os.path.join(LIBDIR, "finrom_api_asan.o")
+    lib = os.path.join(LIBDIR, "libfinrom_hip_asan.so")
+    san = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer"]
+    src = os.path.join(CSRC, "finrom_api.hip")
+    if _stale(obj, [src] + HEADERS):
+        r = subprocess.run([hipcc, *FLAGS, "-O1", "-g", *san, "-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (asan) failed:\n" + r.stdout + r.stderr)
+    others = [os.path.join(LIBDIR, s_.replace(".hip", ".o")) for s_ in SOURCES if s_ != "finrom_api.hip"]
+    if _stale(lib, [obj] + others):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *san[:2], "-o", lib, obj, *others], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (asan link) failed:\n" + r.stdout + r.stderr)
+    return lib
+
+
+def asan_runtime():
+    """clang's shared ASan runtime to LD_PRELOAD into the Python process that loads the ASan build.  It carries the UBSan
+    handlers too; preloading libclang_rt.ubsan_standalone beside it hangs the process at start-up."""
+    import glob
+    base = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(_hipcc()))), "lib", "llvm", "lib", "clang")
+    out = []
+    for pat in ("libclang_rt.asan-x86_64.so",):
+        hits = sorted(glob.glob(os.path.join(base, "*", "lib", "linux", pat)))
+        if hits:
+            out.append(hits[-1])
+    return out

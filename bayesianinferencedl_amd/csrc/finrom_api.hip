@@ -327,7 +327,8 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
     if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;
     return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, qoi, w, info, st);
   }
-  if (h->band.on && getenv("FINROM_NO_BAND") == nullptr) {
+  static const bool env_no_band = getenv("FINROM_NO_BAND") != nullptr;
+  if (h->band.on && !env_no_band) {
     const BandDev& b = h->band;
     const int64_t limit = fom_chunk_samples(d, &b);
     const int64_t npieces = (S + limit - 1) / limit;
@@ -1043,7 +1044,8 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   // band sweep as the FOM half (HBM-bound, one 300-register wave per SIMD, vector units 80 % idle) a projection wave fits beside
   // every sweep wave, and since the projection hides its non-MFMA work behind its own MFMAs a lone wave per SIMD is efficient:
   // measured 26.3 ms side by side against 29.1 ms in turn per 100k samples (r = 80).
-  const bool overlap = g_overlap && getenv("FINROM_NO_OVERLAP") == nullptr;
+  static const bool env_no_overlap = getenv("FINROM_NO_OVERLAP") != nullptr;      // (read once, not per call)
+  const bool overlap = g_overlap && !env_no_overlap;
   hipStream_t side = overlap ? rom->side : st;
   const bool tracing = trace_prefix() != nullptr;
   if (tracing) {
@@ -1064,19 +1066,22 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   // register ranges, so they claim their slots before the small FOM waves fill the remaining ones
   // The FOM's short bandwidth-bound pre-pass (pack + assembly) runs first, alone; beside the projection kernel it
   // would crawl and hold back the interpreter, whose waves then start late.
+  // Every workspace the two halves need is reserved BEFORE the fork: an allocation failure after it would return while the
+  // side stream still writes the caller's outputs.  Any other failure after the fork joins the side stream first.
   const bool split = S <= fom_chunk_samples(fom->d, &fom->band);
-  if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return rc;
+  auto join = [&]() {
+    if (overlap && hipEventRecord(rom->ev_join, side) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join, 0);
+  };
+  auto fail = [&](int code) { if (overlap) (void)hipStreamSynchronize(side); return code; };
+  if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return rc;          // (reserves the FOM workspace)
   if (overlap && split) {                 // the ROM half starts after the pre-pass
     FR_HIP(hipEventRecord(rom->ev_fork, st));
     FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
   }
-  if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, side))) return rc;
-  if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return rc;
-  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, split ? 2 : 3))) return rc;
-  if (overlap) {
-    FR_HIP(hipEventRecord(rom->ev_join, side));
-    FR_HIP(hipStreamWaitEvent(st, rom->ev_join, 0));
-  }
+  if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, side))) return fail(rc);
+  if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return fail(rc);
+  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, split ? 2 : 3))) return fail(rc);
+  join();
   if (err && (rc = launch_sub(qoi, qoi_r, S * (int64_t)fom->d.n_obs, err, st))) return rc;
   if (tracing) {
     if (fom->d.trace) trace_dump("fom", g_trace_buf[0], (size_t)((S + 63) / 64));

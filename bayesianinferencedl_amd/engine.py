@@ -89,6 +89,15 @@ class _Batch:
         return a[2][off:off + n].view(np.float64 if dtype == "f8" else np.int32).reshape(shape)
 
 
+def _sync_if_mixed(b, other):
+    """A torch-stream call that also consumed a NumPy operand staged through a pooled DeviceBuffer: the kernels may still be
+    running on torch's (non-blocking) stream when that buffer goes back to the free list and the next from_numpy overwrites
+    it on the null stream.  Synchronise the launch stream first (results of a pure NumPy call are copied back synchronously,
+    a pure torch call stages nothing)."""
+    if b.torch and not other.torch:
+        check(lib().finrom_stream_sync(b.stream), "finrom_stream_sync")
+
+
 def _csr_rows(M):
     M = sp.csr_matrix(M)
     M.sort_indices()
@@ -235,6 +244,7 @@ class FomEngine:
         db = _Batch(data, self.n_obs)
         grad, gp = b.new((S, self.xdim)); J, Jp = b.new((S,)); qoi, qp = b.new((S, self.n_obs)); info, ip = b.new((S,), "i4")
         check(lib().finrom_fom_gradient(self._h, b.ptr, db.ptr, per_sample, S, gp, Jp, qp, ip, b.stream), "finrom_fom_gradient")
+        _sync_if_mixed(b, db)
         return {"grad": b.out(grad, (S, self.xdim)), "J": b.out(J, (S,)), "qoi": b.out(qoi, (S, self.n_obs)),
                 "info": b.out(info, (S,), "i4")}
 
@@ -327,6 +337,7 @@ class RomEngine:
         J, Jp = b.new((S,)); g, gp = b.new((S, self.P)); w_r, wp = b.new((S, self.r))
         qoi, qp = b.new((S, self.n_obs)); info, ip = b.new((S,), "i4")
         check(lib().finrom_rom_grad(self._h, b.ptr, db.ptr, per_sample, S, Jp, gp, wp, qp, ip, b.stream), "finrom_rom_grad")
+        _sync_if_mixed(b, db)
         return {"J": b.out(J, (S,)), "g": b.out(g, (S, self.P)), "w_r": b.out(w_r, (S, self.r)),
                 "qoi_r": b.out(qoi, (S, self.n_obs)), "info": b.out(info, (S,), "i4")}
 

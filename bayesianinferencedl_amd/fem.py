@@ -163,25 +163,34 @@ class FunctionSpace:
 
 
 class _Vector:
-    """The slice of dolfin's GenericVector API the callers use."""
+    """The slice of dolfin's GenericVector API the callers use.  Every write invalidates what the owning Function carries about
+    its old state (the observables the solve kernel computed for it)."""
 
-    def __init__(self, a):
+    def __init__(self, a, owner=None):
         self._a = a
+        self._owner = owner
+
+    def _touch(self):
+        if self._owner is not None:
+            self._owner._qoi = None
 
     def set_local(self, values):
         self._a[:] = np.asarray(values, dtype=np.float64).reshape(self._a.shape)
+        self._touch()
 
     def get_local(self):
         return self._a.copy()
 
     def axpy(self, alpha, other):
         self._a += alpha * (other._a if isinstance(other, _Vector) else np.asarray(other))
+        self._touch()
 
     def __getitem__(self, idx):
         return self._a[idx].copy() if isinstance(idx, slice) else self._a[idx]
 
     def __setitem__(self, idx, v):
         self._a[idx] = v
+        self._touch()
 
     def __len__(self):
         return len(self._a)
@@ -194,14 +203,16 @@ class Function:
     def __init__(self, V: FunctionSpace, values=None):
         self.V = V
         self._a = np.zeros(V.dim())
+        self._qoi = None                 # B_obs w as computed by the solve kernel, valid only while the state is untouched
         if values is not None:
             self._a[:] = values
 
     def vector(self):
-        return _Vector(self._a)
+        return _Vector(self._a, self)
 
     def assign(self, other):
         self._a[:] = other._a if isinstance(other, Function) else np.asarray(other)
+        self._qoi = None
 
     def function_space(self):
         return self.V

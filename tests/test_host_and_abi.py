@@ -289,3 +289,35 @@ def test_sampler_rejects_a_lower_triangular_factor():
     h = C.c_void_p()
     rc = _ffi.lib().finrom_sampler_create(np.ascontiguousarray(L).ctypes.data_as(_ffi.c_f64p), 5, C.byref(h))
     assert rc == -1 and b"upper" in _ffi.lib().finrom_last_error()
+
+
+def test_validators_under_address_sanitizer():
+    """SURVEY 5 (race / memory checking of the host layer): the C-ABI's create-time validators run under an AddressSanitizer +
+    UBSan build of csrc/finrom_api.hip (host code only) on the CPU box, fed corrupt descriptors by tools/asan_validators.py."""
+    from bayesianinferencedl_amd import _build
+    lib = _build.build_asan()
+    rt = _build.asan_runtime()
+    assert rt, "clang's shared ASan runtime not found"
+    env = dict(os.environ, LD_PRELOAD=":".join(rt), FINROM_LIB=lib, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_validators.py")], capture_output=True, text=True,
+                       timeout=240, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "ASAN-VALIDATORS-OK" in r.stdout
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_function_writes_invalidate_the_cached_observables(spaces):
+    """Fin.forward attaches the kernel's B_obs w to the returned Function; qoi_operator may only use it while the
+    state is untouched -- set_local / axpy / __setitem__ / assign must drop it (the reference always computes B_obs @ w)."""
+    from bayesianinferencedl_amd.fem import Function
+    V = spaces(4)
+    for mutate in (lambda f: f.vector().set_local(np.ones(V.dim())), lambda f: f.vector().axpy(2.0, np.ones(V.dim())),
+                   lambda f: f.vector().__setitem__(3, 7.0), lambda f: f.assign(np.arange(V.dim(), dtype=float))):
+        f = Function(V, np.zeros(V.dim()))
+        f._qoi = np.arange(9.0)
+        mutate(f)
+        assert f._qoi is None
+    f = Function(V); f._qoi = np.arange(9.0)
+    _ = f.vector()[:]; _ = f.vector().get_local()            # reads keep it
+    assert f._qoi is not None
