@@ -56,6 +56,15 @@ class FomBandDesc(C.Structure):
                 ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p)]
 
 
+c_f32p = C.POINTER(C.c_float)
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_in", C.c_int32), ("n_w", C.c_int32), ("n_layers", C.c_int32), ("n_out", C.c_int32),
+                ("W0", c_f32p), ("b0", c_f32p), ("scale", c_f32p), ("shift", c_f32p), ("W", c_f32p), ("b", c_f32p),
+                ("Wh", c_f32p), ("bh", c_f32p)]
+
+
 class RomDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("r", C.c_int32), ("P", C.c_int32), ("n_obs", C.c_int32),
                 ("nterms", C.c_int32),
@@ -100,6 +109,10 @@ SIGNATURES = {
     "finrom_sampler_destroy": (None, [C.c_void_p]),
     "finrom_sampler_draw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "finrom_sampler_draw_seeded": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finrom_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_void_p)]),
+    "finrom_mlp_destroy": (None, [C.c_void_p]),
+    "finrom_mlp_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "finrom_romml_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 6),
     "finrom_solve_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 8),
     "finrom_sub": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }
@@ -126,7 +139,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 6:
+        if L.finrom_version() != 7:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -95,6 +95,7 @@ struct finrom_rom_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 struct finrom_sampler_s { double* U = nullptr; int n = 0; Scratch xi; };
+struct finrom_mlp_s { MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp; };
 
 template <class T>
 static int up(std::vector<void*>& owned, const T** dst, const T* host, size_t count) {
@@ -1126,6 +1127,66 @@ int finrom_sampler_draw_seeded(finrom_sampler_t h, uint64_t seed, int64_t first_
     if (rc) return rc;
   }
   return 0;
+}
+
+int finrom_mlp_create(const finrom_mlp_desc* a, finrom_mlp_t* out) {
+  if (!a || !out) { set_error("mlp_create: null argument"); return FINROM_ERR_ARG; }
+  *out = nullptr;
+  if (a->n_in <= 0 || a->n_w <= 0 || a->n_w > 64 || a->n_layers < 0 || a->n_layers > 64 || a->n_out <= 0 || a->n_out > 64 ||
+      !a->W0 || !a->b0 || !a->scale || !a->shift || !a->Wh || !a->bh || (a->n_layers > 0 && (!a->W || !a->b))) {
+    set_error("mlp_create: inconsistent sizes (n_w, n_out <= 64)"); return FINROM_ERR_ARG;
+  }
+  auto* h = new finrom_mlp_s();
+  MlpDev& d = h->d;
+  d.n_in = a->n_in; d.n_w = a->n_w; d.n_layers = a->n_layers; d.n_out = a->n_out;
+  int rc = 0;
+  const size_t nw = a->n_w, L = a->n_layers;
+  if (!rc) rc = up(h->owned, &d.W0, a->W0, (size_t)a->n_in * nw);
+  if (!rc) rc = up(h->owned, &d.b0, a->b0, nw);
+  if (!rc) rc = up(h->owned, &d.scale, a->scale, (L + 1) * nw);
+  if (!rc) rc = up(h->owned, &d.shift, a->shift, (L + 1) * nw);
+  if (!rc) rc = up(h->owned, &d.W, a->W, L * nw * nw);
+  if (!rc) rc = up(h->owned, &d.b, a->b, L * nw);
+  if (!rc) rc = up(h->owned, &d.Wh, a->Wh, nw * a->n_out);
+  if (!rc) rc = up(h->owned, &d.bh, a->bh, (size_t)a->n_out);
+  if (rc) { finrom_mlp_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+void finrom_mlp_destroy(finrom_mlp_t h) {
+  if (!h) return;
+  for (void* p : h->owned) (void)hipFree(p);
+  h->tape.release(); h->theta.release(); h->gth.release(); h->shift.release(); h->qtmp.release(); h->etmp.release();
+  delete h;
+}
+int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, void* stream) {
+  if (!h || S < 0 || (S > 0 && (!k || !e))) { set_error("mlp_predict: bad argument"); return FINROM_ERR_ARG; }
+  int rc = h->tape.reserve((size_t)S * (h->d.n_layers + 1) * h->d.n_w * sizeof(float));
+  if (rc) return rc;
+  return launch_mlp_forward(h->d, k, S, nullptr, 0, (float*)h->tape.p, e, nullptr, (hipStream_t)stream);
+}
+int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
+                      int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
+                      int32_t* info, void* stream) {
+  if (!rom || !mlp || !Sop || S < 0 || (S > 0 && (!k || !data || !grad || !loss))) { set_error("romml_grad: bad argument"); return FINROM_ERR_ARG; }
+  const MlpDev& m = mlp->d;
+  if (m.n_out != rom->d.n_obs) { set_error("romml_grad: the error model's outputs are not the ROM's observables"); return FINROM_ERR_ARG; }
+  if (S == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = rom->d.P, no = m.n_out;
+  int rc;
+  if ((rc = mlp->tape.reserve((size_t)S * (m.n_layers + 1) * m.n_w * sizeof(float)))) return rc;
+  if ((rc = mlp->theta.reserve((size_t)S * P * sizeof(double)))) return rc;
+  if ((rc = mlp->gth.reserve((size_t)S * P * sizeof(double)))) return rc;
+  if ((rc = mlp->shift.reserve((size_t)S * no * sizeof(double)))) return rc;
+  if (!qoi_r) { if ((rc = mlp->qtmp.reserve((size_t)S * no * sizeof(double)))) return rc; qoi_r = (double*)mlp->qtmp.p; }
+  if (!e_nn) { if ((rc = mlp->etmp.reserve((size_t)S * no * sizeof(double)))) return rc; e_nn = (double*)mlp->etmp.p; }
+  const int64_t stride = data_per_sample ? no : 0;
+  if ((rc = launch_subfin_avg(Sop, P, m.n_in, k, S, (double*)mlp->theta.p, st))) return rc;
+  if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st))) return rc;
+  if ((rc = finrom_rom_grad(rom, (const double*)mlp->theta.p, (const double*)mlp->shift.p, 1, S, loss, (double*)mlp->gth.p, nullptr,
+                            qoi_r, info, st))) return rc;
+  return launch_mlp_backward(m, S, (const float*)mlp->tape.p, data, stride, qoi_r, e_nn, (const double*)mlp->gth.p, Sop, P, grad, st);
 }
 
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {

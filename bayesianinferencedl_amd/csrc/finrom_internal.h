@@ -141,6 +141,19 @@ struct BandDev {
 bool band_supported(int NSF, int NSP, int NX);
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st);
 
+// ---- learned error model (mlp_kernels.hip, finrom_mlp_*) ----------------------------------
+struct MlpDev {
+  int n_in, n_w, n_layers, n_out;
+  const float* W0; const float* b0;            // [n_in x n_w], [n_w]
+  const float* scale; const float* shift;      // [(n_layers + 1) x n_w] inference-form batch normalisation (last row: the head)
+  const float* W; const float* b;              // [n_layers x n_w x n_w], [n_layers x n_w]
+  const float* Wh; const float* bh;            // [n_w x n_out], [n_out]
+};
+int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double* data, int64_t data_stride, float* tape,
+                       double* e_out, double* data_shift, hipStream_t st);
+int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
+                        const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st);
+
 // ---- ROM ------------------------------------------------------------------------------
 constexpr int ROM_MAX_PHASES = 8;
 struct RomDev {

@@ -1,0 +1,132 @@
+// The learned error model on the device: the reference evaluates a Keras residual batch-normalised fully
+// connected network e_NN(k): R^n -> R^n_obs (deep_learning/dl_model.py:149-176 `res_bn_fc_model`) and its input gradient
+// (tf.gradients(loss, model.input), rom/averaged_affine_ROM.py:225-228, 381-395) once per MAP / HMC step, in fp32.
+//     y0 = W0^T x + b0;   y_{i+1} = y_i + W_i^T elu(s_i y_i + t_i) + b_i  (i < L);   out = W_h^T elu(s_h y_L + t_h) + b_h
+// (batch normalisation in inference form: s = gamma / sqrt(var + eps), t = beta - mean s; the first BN-activation-Dense triple of
+// the reference's residual_unit is dead code, :150-158).
+// One workgroup per sample (the call pattern is S = 1 .. a few chains: latency, not throughput): x in LDS, the first layer
+// split over 5 threads per hidden unit, the 50 x 50 layers one thread per output.  Forward keeps the pre-activations
+// ("tape", (L + 1) x n_w floats per sample) for the backward kernel, which runs after the ROM adjoint (its upstream is the
+// residual data - (qoi_r + e_NN)) and also adds the ROM part g_theta^T S, so that the final gradient is written once.
+#include "finrom_internal.h"
+
+namespace finrom {
+
+__device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
+__device__ __forceinline__ float elu_grad_f(float z) { return z > 0.f ? 1.f : expf(z); }
+
+constexpr int MLP_MAX_W = 64;        // hidden width (reference: 50 / 100 -> 64 covers load_bn_model's models; checked at create)
+constexpr int MLP_PARTS = 4;         // threads per hidden unit in the first layer (256 threads = 64 units x 4 parts)
+
+// e_out[s][o] (double) = network output; data_shift[s][o] = data[o] - e_out (what the ROM adjoint is run against)
+__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev m, const double* __restrict__ k, int64_t S,
+                                                          const double* __restrict__ data, int64_t data_stride,
+                                                          float* __restrict__ tape, double* __restrict__ e_out,
+                                                          double* __restrict__ data_shift) {
+  extern __shared__ float xs[];                        // [n_in] input, then scratch
+  __shared__ float part[MLP_PARTS][MLP_MAX_W];
+  __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
+  const int64_t s = blockIdx.x;
+  const int tid = threadIdx.x, nw = m.n_w;
+  for (int i = tid; i < m.n_in; i += 256) xs[i] = (float)k[s * m.n_in + i];
+  __syncthreads();
+  {                                                   // y0 = W0^T x + b0: unit j = tid % 64, part p = tid / 64 of the rows
+    const int j = tid & 63, p = tid >> 6;
+    float acc = 0.f;
+    if (j < nw) {
+      const int i0 = (int)((int64_t)m.n_in * p / MLP_PARTS), i1 = (int)((int64_t)m.n_in * (p + 1) / MLP_PARTS);
+      for (int i = i0; i < i1; ++i) acc = fmaf(xs[i], m.W0[(int64_t)i * nw + j], acc);
+    }
+    part[p][j] = acc;
+  }
+  __syncthreads();
+  if (tid < nw) y[tid] = m.b0[tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+  __syncthreads();
+  float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
+  for (int l = 0; l <= m.n_layers; ++l) {              // l == n_layers: the head
+    const float* sc = m.scale + l * nw; const float* sh = m.shift + l * nw;
+    if (tid < nw) { const float z = fmaf(y[tid], sc[tid], sh[tid]); tp[l * nw + tid] = z; a[tid] = elu_f(z); }
+    __syncthreads();
+    if (l < m.n_layers) {
+      const float* W = m.W + (int64_t)l * nw * nw;
+      if (tid < nw) {
+        float acc = m.b[l * nw + tid];
+        for (int i = 0; i < nw; ++i) acc = fmaf(a[i], W[i * nw + tid], acc);
+        y[tid] += acc;
+      }
+    } else if (tid < m.n_out) {
+      float acc = m.bh[tid];
+      for (int i = 0; i < nw; ++i) acc = fmaf(a[i], m.Wh[i * m.n_out + tid], acc);
+      e_out[s * m.n_out + tid] = (double)acc;
+      if (data_shift != nullptr) data_shift[s * m.n_out + tid] = data[(data_stride ? s * data_stride : 0) + tid] - (double)acc;
+    }
+    __syncthreads();
+  }
+}
+
+// grad[s][i] = sum_p g_theta[s][p] Sop[p][i]  -  sum_j g0[j] W0[i][j],  g0 = d(1/2 |r|^2)/d(y0) with upstream r = data - (qoi_r + e)
+// loss[s] = 1/2 |r|^2 is recomputed here from the same residual (the ROM kernel's J is that of the shifted data: the same number)
+__global__ __launch_bounds__(256) void mlp_backward_kernel(MlpDev m, int64_t S, const float* __restrict__ tape,
+                                                           const double* __restrict__ data, int64_t data_stride,
+                                                           const double* __restrict__ qoi_r, const double* __restrict__ e_nn,
+                                                           const double* __restrict__ g_theta, const double* __restrict__ Sop,
+                                                           int P, double* __restrict__ grad) {
+  __shared__ float g[MLP_MAX_W], gn[MLP_MAX_W], up[MLP_MAX_W];
+  __shared__ double gth[32];
+  const int64_t s = blockIdx.x;
+  const int tid = threadIdx.x, nw = m.n_w;
+  const float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
+  if (tid < m.n_out) {
+    const double r = data[(data_stride ? s * data_stride : 0) + tid] - (qoi_r[s * m.n_out + tid] + e_nn[s * m.n_out + tid]);
+    up[tid] = (float)r;                                // dLoss/d(output) handed to vjp is +r; the minus sign comes at the end
+  }
+  if (tid < P) gth[tid] = g_theta != nullptr ? g_theta[s * P + tid] : 0.0;
+  __syncthreads();
+  if (tid < nw) {                                      // through the head: no skip connection
+    float acc = 0.f;
+    for (int o = 0; o < m.n_out; ++o) acc = fmaf(up[o], m.Wh[tid * m.n_out + o], acc);
+    const float z = tp[m.n_layers * nw + tid];
+    g[tid] = acc * elu_grad_f(z) * m.scale[m.n_layers * nw + tid];
+  }
+  __syncthreads();
+  for (int l = m.n_layers - 1; l >= 0; --l) {          // g <- g + (W_l g) * elu'(z_l) * s_l   (skip + branch)
+    const float* W = m.W + (int64_t)l * nw * nw;
+    if (tid < nw) {
+      float acc = 0.f;
+      for (int j = 0; j < nw; ++j) acc = fmaf(g[j], W[tid * nw + j], acc);
+      gn[tid] = g[tid] + acc * elu_grad_f(tp[l * nw + tid]) * m.scale[l * nw + tid];
+    }
+    __syncthreads();
+    if (tid < nw) g[tid] = gn[tid];
+    __syncthreads();
+  }
+  for (int i = tid; i < m.n_in; i += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < nw; ++j) acc = fmaf(g[j], m.W0[(int64_t)i * nw + j], acc);
+    double out = -(double)acc;                         // d loss / d input = -vjp(r)
+    for (int p = 0; p < P; ++p) out = fma(gth[p], Sop[(int64_t)p * m.n_in + i], out);
+    grad[s * m.n_in + i] = out;
+  }
+}
+
+int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double* data, int64_t data_stride, float* tape,
+                       double* e_out, double* data_shift, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_MISC, st);
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)S), dim3(256), (size_t)m.n_in * sizeof(float), st, m, k, S, data, data_stride,
+                     tape, e_out, data_shift);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
+                        const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_MISC, st);
+  hipLaunchKernelGGL(mlp_backward_kernel, dim3((unsigned)S), dim3(256), 0, st, m, S, tape, data, data_stride, qoi_r, e_nn, g_theta,
+                     Sop, P, grad);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace finrom

@@ -10,7 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _ffi
-from ._ffi import FomBandDesc, FomSmallDesc, DeviceBuffer, FomDesc, FomGradDesc, RomDesc, check, f64, i32, lib
+from ._ffi import FomBandDesc, FomSmallDesc, DeviceBuffer, FomDesc, FomGradDesc, MlpDesc, RomDesc, check, f64, i32, lib
 
 
 import os as _os
@@ -405,6 +405,65 @@ class FieldSampler:
             self.close()
         except Exception:
             pass
+
+
+class DeviceErrorModel:
+    """The learned error model on the device (finrom_mlp_*): the weights of a deep_learning/dl_model.py::ResBnFcModel (the
+    stand-in for the reference's Keras res_bn_fc_model, dl_model.py:149-176), batch normalisation folded into scale / shift in
+    fp32 exactly as the host model does."""
+
+    def __init__(self, model):
+        from .deep_learning.dl_model import BN_EPS
+        layers = list(model.units) + [model.head]
+        f32 = lambda a_: np.ascontiguousarray(a_, dtype=np.float32)
+        scale = np.stack([u["gamma"] / np.sqrt(u["var"] + np.float32(BN_EPS)) for u in layers]).astype(np.float32)
+        shift = np.stack([u["beta"] - u["mean"] * s_ for u, s_ in zip(layers, scale)]).astype(np.float32)
+        L, nw = len(model.units), model.n_weights
+        arrs = {"W0": f32(model.W0), "b0": f32(model.b0), "scale": f32(scale), "shift": f32(shift),
+                "W": f32(np.stack([u["W"] for u in model.units]) if L else np.zeros((0, nw, nw))),
+                "b": f32(np.stack([u["b"] for u in model.units]) if L else np.zeros((0, nw))),
+                "Wh": f32(model.head["W"]), "bh": f32(model.head["b"])}
+        self.n_in, self.n_out = model.n_in, model.n_out
+        d = MlpDesc(n_in=model.n_in, n_w=nw, n_layers=L, n_out=model.n_out,
+                    **{k: v.ctypes.data_as(_ffi.c_f32p) for k, v in arrs.items()})
+        h = C.c_void_p()
+        check(lib().finrom_mlp_create(C.byref(d), C.byref(h)), "finrom_mlp_create")
+        self._h = h
+
+    def predict(self, K):
+        b = _Batch(K, self.n_in)
+        e, ep = b.new((b.S, self.n_out))
+        check(lib().finrom_mlp_predict(self._h, b.ptr, b.S, ep, b.stream), "finrom_mlp_predict")
+        return b.out(e, (b.S, self.n_out))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().finrom_mlp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def romml_grad(rom, mlp, Sop_buf, K, data):
+    """finrom_romml_grad: value and gradient of the ROM + learned-error misfit for a batch of nodal fields K [S, n] in ONE
+    library call (sub-fin averages, network forward, ROM adjoint against data - e_NN, network backward + chain rule).
+    -> dict(grad [S, n], loss [S], qoi_r, e_NN, info)."""
+    n, n_obs = mlp.n_in, mlp.n_out
+    b = _Batch(K, n)
+    S = b.S
+    data = data if _is_torch(data) else np.ascontiguousarray(data, dtype=np.float64)
+    per_sample = 1 if data.ndim == 2 else 0
+    db = _Batch(data, n_obs)
+    grad, gp = b.new((S, n)); loss, lp = b.new((S,)); q, qp = b.new((S, n_obs)); e, ep = b.new((S, n_obs)); info, ip = b.new((S,), "i4")
+    check(lib().finrom_romml_grad(rom._h, mlp._h, Sop_buf.ptr, b.ptr, db.ptr, per_sample, S, gp, lp, qp, ep, ip, b.stream),
+          "finrom_romml_grad")
+    _sync_if_mixed(b, db)
+    return {"grad": b.out(grad, (S, n)), "loss": b.out(loss, (S,)), "qoi_r": b.out(q, (S, n_obs)), "e_NN": b.out(e, (S, n_obs)),
+            "info": b.out(info, (S,), "i4")}
 
 
 def device_sub(a, b_):

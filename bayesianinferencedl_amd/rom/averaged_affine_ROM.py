@@ -15,7 +15,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from ..fem import BIOT, Function, as_nodal, deterministic_blas
-from ..engine import FomEngine, RomEngine, SubfinAverager
+from ..engine import DeviceErrorModel, FomEngine, RomEngine, SubfinAverager, romml_grad
 from ..fom.forward_solve import _plan_for, external_observation_matrix
 
 
@@ -51,7 +51,8 @@ class AffineROMFin:
         # at n = 1446; kept sparse here -- see .dA_dsigmak)
         self._A_sub = [ops.csr(ops.sub_vals[i]) for i in range(9)]
         self.dA_dsigmak_phi = np.stack([A @ self.phi for A in self._A_sub])
-        self.dl_model = err_model
+        self.dl_model = None
+        self._dev_model = None
         self.data = None
         self.psi = None
         self._state = None                                      # (A_r, B_r) of the last scalar solve, computed on demand
@@ -66,6 +67,7 @@ class AffineROMFin:
         self._psi_tables = [robin_phi] + [self.dA_dsigmak_phi[i] for i in range(9)]
         self.projection = "direct"
         self.set_projection(projection or os.environ.get("FINROM_PROJECTION", "direct"))
+        self.set_dl_model(err_model)
 
     def set_projection(self, mode):
         """How the reduced operator is formed per sample.  'direct' (default): psi = A(theta) Phi, A_r = psi^T psi on the
@@ -211,11 +213,21 @@ class AffineROMFin:
     def grad_romml_batch(self, K, data=None):
         """Batched grad_romml (:358-396): ROM + learned-error value and gradient.  loss = 1/2 |data - (B_obs Phi w_r + e_NN(k))|^2;
         its gradient is the ROM adjoint gradient for the shifted data (data - e_NN) plus the network's vector-Jacobian
-        product.  K [S, n] -> dict(grad [S, n], loss [S], qoi_r, e_NN, info)."""
+        product.  K [S, n] -> dict(grad [S, n], loss [S], qoi_r, e_NN, info).
+        With a ResBnFcModel (deep_learning/dl_model.py) as the error model everything runs on the device in ONE library call
+        (finrom_romml_grad: network forward, ROM adjoint, network backward, chain rule through the sub-fin averages); any other
+        object with predict / vjp (a Keras wrapper, say) is evaluated where it lives, around the device ROM adjoint."""
         if self.dl_model is None:
             raise ValueError("grad_romml needs an error model (set_dl_model)")
+        data = self.data if data is None else data
+        if self._dev_model is not None:
+            self._ensure_gradient()
+            t_i = time.time()
+            res = romml_grad(self._rom, self._dev_model, self._avg._S, K, data)
+            self.romml_grad_time += (time.time() - t_i)
+            return res
         K = np.ascontiguousarray(K, dtype=np.float64)
-        data = np.asarray(self.data if data is None else data, dtype=np.float64)
+        data = np.asarray(data, dtype=np.float64)
         t_i = time.time()
         e_nn = np.asarray(self.dl_model.predict(K), dtype=np.float64)
         self.romml_grad_time_dl += (time.time() - t_i)
@@ -238,8 +250,15 @@ class AffineROMFin:
     def set_data(self, data):
         self.data = data
 
-    def set_dl_model(self, model):
+    def set_dl_model(self, model, device=True):
+        """A ResBnFcModel whose hidden width the library supports goes to the device (device=False keeps it on the host, e.g.
+        for A/B checks); other models are called on the host."""
+        from ..deep_learning.dl_model import ResBnFcModel
         self.dl_model = model
+        self._dev_model = None
+        if device and isinstance(model, ResBnFcModel) and model.n_weights <= 64 and model.n_out <= 64 and model.n_in == self.n \
+                and model.n_out == self.n_obs:
+            self._dev_model = DeviceErrorModel(model)
 
     def subfin_avg_op(self, k):
         return np.asarray(self.subfin_avg_batch(as_nodal(k)[None, :]))[0]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 6
+#define FINROM_ABI_VERSION 7
 
 typedef enum {
   FINROM_OK = 0,
@@ -45,6 +45,7 @@ typedef enum {
 typedef struct finrom_fom_s* finrom_fom_t;
 typedef struct finrom_rom_s* finrom_rom_t;
 typedef struct finrom_sampler_s* finrom_sampler_t;
+typedef struct finrom_mlp_s* finrom_mlp_t;
 
 int finrom_version(void);
 const char* finrom_last_error(void);
@@ -270,6 +271,29 @@ int finrom_rom_set_gradient(finrom_rom_t h, int32_t npairs, const int32_t* pair_
                             const double* G);
 int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int32_t data_per_sample,
                     int64_t S, double* J, double* g, double* w_r, double* qoi_r, int32_t* info, void* stream);
+
+/* ---- learned error model + ROM: value and gradient of the ROM+ML misfit -------------------------------------------- *
+ * AffineROMFin.grad_romml (rom/averaged_affine_ROM.py:358-396) for S conductivity fields in one call:
+ *   e_NN = model(k) (fp32, the reference's Keras res_bn_fc_model, deep_learning/dl_model.py:149-176, batch normalisation in
+ *   inference form),  theta = Sop k,  ROM adjoint against data - e_NN  ->  loss = 1/2 |data - (qoi_r + e_NN)|^2  and
+ *   grad = (dJ/dtheta)^T Sop  -  (d e_NN / d k)^T (data - (qoi_r + e_NN))     (:376-395)
+ * finrom_mlp_create copies the weights (host pointers, fp32, row-major as listed); n_w <= 64, n_out <= 64.
+ * finrom_romml_grad: k [S x n] device, data [n_obs] (data_per_sample = 0) or [S x n_obs]; outputs grad [S x n], loss [S],
+ * optional qoi_r / e_nn [S x n_obs] (NULL to skip); Sop [P x n] device (the sub-fin averaging operator = dsigma_dk);
+ * finrom_rom_set_gradient must have been called on `rom`.  finrom_mlp_predict: e [S x n_out] only (:360). */
+typedef struct {
+  int32_t n_in, n_w, n_layers, n_out;
+  const float* W0; const float* b0;            /* [n_in x n_w], [n_w]                                  y0 = x W0 + b0 */
+  const float* scale; const float* shift;      /* [(n_layers + 1) x n_w]  gamma / sqrt(var + eps), beta - mean * scale; last row: head */
+  const float* W; const float* b;              /* [n_layers x n_w x n_w], [n_layers x n_w]             y += elu(bn(y)) W_i + b_i */
+  const float* Wh; const float* bh;            /* [n_w x n_out], [n_out]                               out = elu(bn(y)) Wh + bh */
+} finrom_mlp_desc;
+int finrom_mlp_create(const finrom_mlp_desc* desc, finrom_mlp_t* out);
+void finrom_mlp_destroy(finrom_mlp_t h);
+int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, void* stream);
+int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
+                      int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
+                      int32_t* info, void* stream);
 
 /* ---- sub-fin averages  theta = S k  (fom :466-480, rom :404-418) -------------------- *
  * Sop is the dense [P x n] averaging operator on the device (finrom_malloc + h2d). */

@@ -420,10 +420,14 @@ def test_grad_romml_parity(problems, spaces, tmp_path):
     ro = O.AffineROMOracle(prob, phi); ro.set_data(data)
     for _ in range(3):
         k = np.exp(0.3 * rng.standard_normal(prob.n))
-        g, loss = rom.grad_romml(Function(V, k))
         go, lo = O.grad_romml_oracle(ro, model, k)
+        rom.set_dl_model(model, device=False)              # network on the host: the oracle's own fp32 GEMV order -> tight
+        g, loss = rom.grad_romml(Function(V, k))
         assert abs(loss - lo) < 1e-9 * lo
         assert np.linalg.norm(g - go) < 1e-7 * np.linalg.norm(go)
+        rom.set_dl_model(model)                             # network on the device (the default): fp32 in another order
+        g, loss = rom.grad_romml(Function(V, k))
+        assert abs(loss - lo) < 2e-5 * lo and np.linalg.norm(g - go) < 1e-5 * np.linalg.norm(go)
     # batched: the fp32 network sums in a different order for a batch (BLAS GEMM vs GEMV) -> fp32-level agreement
     K = np.exp(0.3 * rng.standard_normal((5, prob.n)))
     res = rom.grad_romml_batch(K)
@@ -501,8 +505,10 @@ def test_sq_error_ops_value_and_gradient(problems, spaces):
         assert np.linalg.norm(op._error_op.obs_data - data) < 1e-10 * np.linalg.norm(data)
         out = [[None], [None]]
         op.perform(None, [k], out)
-        assert abs(float(out[0][0]) - want[0]) < 1e-8 * abs(want[0])
-        assert np.linalg.norm(out[1][0] - want[1]) < 1e-6 * np.linalg.norm(want[1])
+        # (ROM+ML: the fp32 network runs on the device in another summation order than the oracle's NumPy copy)
+        vtol, gtol = (2e-5, 1e-5) if Op is SqErrorOpROMML else (1e-8, 1e-6)
+        assert abs(float(out[0][0]) - want[0]) < vtol * abs(want[0])
+        assert np.linalg.norm(out[1][0] - want[1]) < gtol * np.linalg.norm(want[1])
         assert np.allclose(op.grad([k], [2.0])[0], 2.0 * out[1][0])
 
 
@@ -523,3 +529,38 @@ def test_device_philox_sampler_matches_the_oracle_and_ignores_the_shard_cut(prob
     a, b = smp.draw(5, 1000, 111), smp.draw(5, 1111, 189)
     assert np.array_equal(np.concatenate([a, b]), k)
     assert not np.array_equal(smp.draw(6, 1000, 4), k[:4])
+
+
+def test_device_error_model_matches_the_host_network(problems, spaces):
+    """f3: the fp32 residual network on the device (finrom_mlp_predict / finrom_romml_grad) against its NumPy original
+    (deep_learning/dl_model.py::ResBnFcModel, the stand-in for the reference's Keras model, dl_model.py:149-176) -- fp32
+    arithmetic in a different summation order: 1e-5 -- and the fused value-and-gradient call against the oracle's dense
+    restatement of rom/averaged_affine_ROM.py:358-396 at m = 12, r = 81."""
+    import bench
+    from bayesianinferencedl_amd.engine import DeviceErrorModel
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    from bayesianinferencedl_amd.rom.basis import pod_basis
+    m, r = 12, 81
+    prob, V = problems(m), spaces(m)
+    model = bench.hmc_error_model(prob.n)
+    rng = np.random.default_rng(3)
+    K = np.exp(0.3 * rng.standard_normal((7, prob.n)))
+    dev = DeviceErrorModel(model)
+    e_dev, e_host = dev.predict(K), model.predict(K).astype(np.float64)
+    assert np.max(np.abs(e_dev - e_host)) <= 1e-5 * np.max(np.abs(e_host))
+    phi = pod_basis(Fin(V), r, n_snapshots=200, low=0.1, high=10.0, params="nine", seed=1)
+    data = rng.uniform(0.2, 1.0, 9)
+    ro = O.AffineROMOracle(prob, phi); ro.set_data(data)
+    for projection in ("direct", "offline_online"):
+        rom = AffineROMFin(V, model, phi, projection=projection); rom.set_data(data)
+        assert rom._dev_model is not None
+        res = rom.grad_romml_batch(K)
+        rom.set_dl_model(model, device=False)               # the same evaluation with the network on the host
+        ref = rom.grad_romml_batch(K)
+        assert (res["info"] == 0).all()
+        for s in range(len(K)):
+            assert abs(res["loss"][s] - ref["loss"][s]) <= 2e-5 * abs(ref["loss"][s])
+            assert np.linalg.norm(res["grad"][s] - ref["grad"][s]) <= 1e-5 * np.linalg.norm(ref["grad"][s])
+        go, lo = O.grad_romml_oracle(ro, model, K[2])
+        assert abs(res["loss"][2] - lo) <= 2e-5 * abs(lo) and np.linalg.norm(res["grad"][2] - go) <= 1e-5 * np.linalg.norm(go)
