@@ -594,9 +594,9 @@ def dry_run(args, rank, world):
 
 def measured_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of this same command
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/r01_pmc_summary.json); None if the
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs, profiles/r02_pmc_summary.json); None if the
     summary is absent or was taken on another workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
         with open(path) as f:
             d = json.load(f)

@@ -16,7 +16,7 @@ raw = {}
 for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            m = re.search(r"finrom::(\w+)", row["Kernel_Name"])
+            m = re.search(r"finrom::(?:\(anonymous namespace\)::)?(\w+)", row["Kernel_Name"])
             if not m:
                 continue
             raw.setdefault(m.group(1), {})[row["Counter_Name"]] = float(row["Counter_Value"])     # last launch wins
@@ -26,7 +26,7 @@ summary = {"workload_key": key,
                    "FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE doubled "
                    "as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE exact).",
            "raw": raw, "hbm_bytes_per_launch": {}, "l2_hit_rate": {}, "mfma_busy_frac": {}}
-slot_of = {"fom_vm_kernel": "fom_chol_solve", "fom_bwd_kernel": "fom_chol_solve", "rom_gram_kernel": "rom_proj_mfma", "rom_gram_store_kernel": "rom_proj_mfma", "fom_assemble_kernel": "fom_assemble", "rom_proj_kernel": "rom_proj_mfma",
+slot_of = {"fom_band_kernel": "fom_chol_solve", "fom_vm_kernel": "fom_chol_solve", "fom_bwd_kernel": "fom_chol_solve", "rom_gram_kernel": "rom_proj_mfma", "rom_gram_store_kernel": "rom_proj_mfma", "fom_assemble_kernel": "fom_assemble", "rom_proj_kernel": "rom_proj_mfma",
            "rom_proj_lds_kernel": "rom_proj_mfma", "rom_proj_kernel_r80": "rom_proj_mfma", "rom_proj_single_kernel": "rom_proj_mfma", "rom_solve_kernel": "rom_reduced_solve", "subfin_avg_kernel": "subfin_avg",
            "pack_kernel": "pack"}
 for k, c in raw.items():
