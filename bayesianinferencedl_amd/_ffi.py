@@ -49,7 +49,7 @@ class FomSmallDesc(C.Structure):
 class FomBandDesc(C.Structure):
     _fields_ = [("NSF", C.c_int32), ("NSP", C.c_int32), ("NX", C.c_int32), ("nfins", C.c_int32), ("npf", C.c_int32),
                 ("nif", C.c_int32), ("npost", C.c_int32), ("nAB", C.c_int32), ("nterms", C.c_int32), ("nLx", C.c_int32),
-                ("ab_c0", c_f64p), ("ab_ptr", c_i32p), ("ab_idx", c_i32p), ("ab_w", c_f64p), ("Fg", c_f64p),
+                ("ab_c0", c_f64p), ("ab_ptr", c_i32p), ("ab_idx", c_i32p), ("ab_w", c_f64p), ("abmap", c_i32p), ("Fg", c_f64p),
                 ("act", c_i32p), ("lx_ptr", c_i32p), ("ent_extra", c_i32p),
                 ("ecp_ptr", c_i32p), ("ecp_slot", c_i32p), ("ecp_off", c_i32p),
                 ("schur_off", c_i32p), ("iface_elim", c_i32p), ("perm", c_i32p),
@@ -139,7 +139,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 7:
+        if L.finrom_version() != 8:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -265,6 +265,31 @@ class BandPlan:
             idx[ptr[e]:ptr[e + 1]] = W_csr.indices[sl]; w[ptr[e]:ptr[e + 1]] = W_csr.data[sl]
         return c0, ptr.astype(np.int32), idx, w
 
+    def compact_slots(self, c0, ptr, idx, w):
+        """Physical value slots: logical slots with the SAME affine record (c0, indices, weights -- exact equality) share one
+        physical slot, except the slots the fins write to (Schur targets, special slots), which stay private.  With the five /
+        nine fin conductivities as parameters 4887 logical slots become ~370 physical ones: the pre-pass writes 3 KB per sample
+        instead of 39 KB and the sweep's value-slot reads hit L2 / MALL instead of HBM.  (A nodal field as parameter vector
+        has almost no duplicates: nothing is lost there.)
+        -> (abmap [nAB] logical -> physical, c0p, ptrp, idxp, wp describing the physical slots)."""
+        private = set(off for tg in self.schur_target for _, _, off in tg)
+        key_to_phys, abmap = {}, np.empty(self.nAB, np.int64)
+        recs = []
+        for e in range(self.nAB):
+            rec = (float(c0[e]), tuple(int(i) for i in idx[ptr[e]:ptr[e + 1]]), tuple(float(v) for v in w[ptr[e]:ptr[e + 1]]))
+            if e in private or e >= 3 * self.G:
+                abmap[e] = len(recs); recs.append(rec)
+                continue
+            if rec not in key_to_phys:
+                key_to_phys[rec] = len(recs); recs.append(rec)
+            abmap[e] = key_to_phys[rec]
+        c0p = np.array([r_[0] for r_ in recs])
+        cnt = np.array([len(r_[1]) for r_ in recs], np.int64)
+        ptrp = np.zeros(len(recs) + 1, np.int64); np.cumsum(cnt, out=ptrp[1:])
+        idxp = np.array([i for r_ in recs for i in r_[1]], np.int32)
+        wp = np.array([v for r_ in recs for v in r_[2]], np.float64)
+        return abmap.astype(np.int32), c0p, ptrp.astype(np.int32), idxp, wp
+
     # ------------------------------------------------------------------------------------------------------------------
     def replay(self, AB, F):
         """NumPy execution of the plan with the device kernel's data flow (cyclic window slots, extras, fin Schur targets,

@@ -477,7 +477,8 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (a->nfins < 0 || a->npf < 0 || a->nif != a->NSF - 1 || a->npost <= 0 || a->nAB <= 0 || a->nterms < 0 || a->nLx < 0) return bad("sizes");
   const int n = d.n, G = a->nfins * (a->npf + a->nif) + a->npost;
   if ((int64_t)a->nfins * a->npf + a->npost != n) return bad("pivot count (must equal the number of dofs)");
-  if (a->nAB < 3 * G) return bad("nAB");
+  if (a->nAB <= 0 || !a->abmap) return bad("nAB / abmap");
+  for (int e = 0; e < 3 * G; ++e) if (a->abmap[e] < 0 || a->abmap[e] >= a->nAB) return bad("abmap");
   const int64_t nL = (int64_t)a->nfins * a->npf * a->NSF + (int64_t)a->npost * a->NSP;
   const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n;
   if (gsize * 512 >= (int64_t)1 << 31) { set_error("fom_set_band: workspace too long for 32-bit buffer offsets"); return FINROM_ERR_UNSUPPORTED; }
@@ -528,6 +529,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (!rc) rc = up(h->owned, &q.asm_rec_d, recd.data(), recd.size());
   if (!rc) rc = up(h->owned, &q.asm_idx, a->ab_idx, a->nterms);
   if (!rc) rc = up(h->owned, &q.asm_w, a->ab_w, a->nterms);
+  if (!rc) rc = up(h->owned, &b.abmap, a->abmap, (size_t)3 * G);
   if (!rc) rc = up(h->owned, &b.Fg, a->Fg, G);
   if (!rc) rc = up(h->owned, &b.act, a->act, a->npost);
   if (!rc) rc = up(h->owned, &b.lx_ptr, a->lx_ptr, a->npost + 1);

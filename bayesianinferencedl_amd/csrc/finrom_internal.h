@@ -135,6 +135,7 @@ struct BandDev {
   int on = 0;
   int n, n_obs, xdim, gsize, nAB, nL, nLx, NSF, NSP, NX, nfins, npf, nif, npost, post_g0, post_e0, post_L0;
   int offL, offLx, offY;
+  const int* abmap;          // [3 G] physical value slot of each entry of a segment node
   const double* Fg; const int* act; const int* lx_ptr; const int* ent_extra; const int* ecp_ptr; const int* ecp_slot; const int* ecp_off;
   const int* schur_off; const int* iface_elim; const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
 };

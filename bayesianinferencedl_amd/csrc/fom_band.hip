@@ -64,7 +64,7 @@ struct PostTables {
 // ---- forward: factorisation fused with L y = F over one segment ----------------------------------------------------------
 template <int NS, bool POST, int NXM>
 __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, double* __restrict__ xs, const double* __restrict__ Fg,
-                                           const PostTables& T, int g0, int e0, int npiv, int ntot, int L0,
+                                           const int* __restrict__ abmap, const PostTables& T, int g0, int e0, int npiv, int ntot, int L0,
                                            double (&win)[NS * (NS + 1) / 2], double (&yw)[NS], int& bad) {
   constexpr int B = NS - 1;
   using L = XL<NS, NXM>;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
     constexpr int u = decltype(uc)::value;
     if (u < ntot) {
       const int g = 3 * (g0 + u);
-      enter(uc, u, io.ld(g), io.ld(g + 1), io.ld(g + 2));
+      enter(uc, u, io.ld(abmap[g]), io.ld(abmap[g + 1]), io.ld(abmap[g + 2]));
     }
   });
 
@@ -188,8 +188,8 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
         else static_for<0, NS>([&](auto vc) { win[tri(u, decltype(vc)::value)] = 0.0; });      // nobody enters: the slot is empty
       }
       if (sidx < npiv && sidx + NS < ntot) {             // entries of the node that enters after pivot s: in flight for RF steps
-        const int g = 3 * (g0 + sidx + NS);
-        ab[rs][0] = io.ld(g); ab[rs][1] = io.ld(g + 1); ab[rs][2] = io.ld(g + 2);
+        const int g = 3 * (g0 + sidx + NS);      // (physical slots: entries with the same affine record share one)
+        ab[rs][0] = io.ld(abmap[g]); ab[rs][1] = io.ld(abmap[g + 1]); ab[rs][2] = io.ld(abmap[g + 2]);
       }
     });
   }
@@ -256,7 +256,8 @@ __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, doub
 }
 
 template <int NSF, int NSP, int NXM>
-__global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const double* __restrict__ Fg, const int* __restrict__ act,
+__global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __restrict__ abmap, const double* __restrict__ Fg,
+                                                      const int* __restrict__ act,
                                                       const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra,
                                                       const int* __restrict__ ecp_ptr, const int* __restrict__ ecp_slot,
                                                       const int* __restrict__ ecp_off, const int* __restrict__ schur_off,
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const double* _
     double win[NSF * (NSF + 1) / 2], yw[NSF];
     for (int f = 0; f < p.nfins; ++f) {
       const int npiv = p.npf, ntot = p.npf + p.nif;
-      band_sweep<NSF, false, NXM>(p, io, xs, Fg, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      band_sweep<NSF, false, NXM>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
       // what is left in the window is the fin's Schur complement on its interface nodes: add it to their entries in the post
       int k = 0;
       for (int t = 0; t < p.nif; ++t)
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const double* _
   }
   {
     double win[NSP * (NSP + 1) / 2], yw[NSP];
-    band_sweep<NSP, true, NXM>(p, io, xs, Fg, T, p.post_g0, p.post_e0, p.npost, p.npost, p.post_L0, win, yw, bad);
+    band_sweep<NSP, true, NXM>(p, io, xs, Fg, abmap, T, p.post_g0, p.post_e0, p.npost, p.npost, p.post_L0, win, yw, bad);
   }
   band_bsweep<NSP, true, NXM>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
   for (int f = 0; f < p.nfins; ++f)
@@ -330,7 +331,7 @@ template <int NSF, int NSP>
 int launch_t(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int NXM = 4;
   const size_t lds = (size_t)XL<NSP, NXM>::SIZE * 64 * sizeof(double);
-  hipLaunchKernelGGL((fom_band_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.Fg, p.act, p.lx_ptr,
+  hipLaunchKernelGGL((fom_band_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.abmap, p.Fg, p.act, p.lx_ptr,
                      p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx, p.obs_w,
                      Gw, S, qoi, info);
   FR_HIP(hipGetLastError());

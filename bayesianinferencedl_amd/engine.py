@@ -164,6 +164,7 @@ class FomEngine:
         if bp is None:
             return
         c0, ptr, idx, w = bp.ab_table(c0_csr, W_csr)
+        abmap, c0p, ptrp, idxp, wp = bp.compact_slots(c0, ptr, idx, w)      # logical -> physical value slots (duplicates shared)
         F = np.asarray(rhs, dtype=np.float64)
         Fg = np.zeros(bp.G)
         for seg in bp.fin_segs + [bp.post_seg]:
@@ -171,7 +172,7 @@ class FomEngine:
         Bp = sp.csr_matrix(np.asarray(B_obs)[:, bp.perm]) if not sp.issparse(B_obs) else sp.csr_matrix(B_obs)[:, bp.perm]
         optr, oidx, ow = _csr_rows(Bp)
         nif = bp.q + 1
-        schur = np.asarray([[off for _, _, off in tg] for tg in bp.schur_target], np.int32)
+        schur = np.asarray([[abmap[off] for _, _, off in tg] for tg in bp.schur_target], np.int32)
         keep = []
 
         def I(a):
@@ -179,10 +180,10 @@ class FomEngine:
 
         def D(a):
             a, p = f64(a); keep.append(a); return p
-        d = FomBandDesc(NSF=bp.NSF, NSP=bp.NSP, NX=bp.NX, nfins=bp.nfins, npf=bp.npf, nif=nif, npost=bp.npost, nAB=bp.nAB,
-                        nterms=len(idx), nLx=bp.nLx, ab_c0=D(c0), ab_ptr=I(ptr), ab_idx=I(idx), ab_w=D(w), Fg=D(Fg),
-                        act=I(bp.act), lx_ptr=I(bp.lx_ptr), ent_extra=I(bp.ent_extra),
-                        ecp_ptr=I(bp.ecp_ptr), ecp_slot=I(bp.ecp_slot), ecp_off=I(bp.ecp_off),
+        d = FomBandDesc(NSF=bp.NSF, NSP=bp.NSP, NX=bp.NX, nfins=bp.nfins, npf=bp.npf, nif=nif, npost=bp.npost, nAB=len(c0p),
+                        nterms=len(idxp), nLx=bp.nLx, ab_c0=D(c0p), ab_ptr=I(ptrp), ab_idx=I(idxp), ab_w=D(wp), abmap=I(abmap[:3 * bp.G]),
+                        Fg=D(Fg), act=I(bp.act), lx_ptr=I(bp.lx_ptr), ent_extra=I(bp.ent_extra),
+                        ecp_ptr=I(bp.ecp_ptr), ecp_slot=I(bp.ecp_slot), ecp_off=I(abmap[bp.ecp_off] if len(bp.ecp_off) else bp.ecp_off),
                         schur_off=I(schur), iface_elim=I(bp.iface_elim), perm=I(bp.perm),
                         obs_ptr=I(optr), obs_idx=I(oidx), obs_w=D(ow))
         rc = lib().finrom_fom_set_band(self._h, C.byref(d))
@@ -190,6 +191,7 @@ class FomEngine:
             return
         check(rc, "finrom_fom_set_band")
         self.band = bp
+        self.band_slots = len(c0p)          # physical value slots per sample (bench: algorithmic bytes)
 
     def solve(self, X, want_w=False):
         b = _Batch(X, self.xdim)

@@ -541,7 +541,8 @@ def roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl)
             bp = eng.band
             # frontal band sweep: value slots read once, every column of L (+ extras) written once and read once, y written and
             # read, w written, QoI out -- nothing else leaves the registers
-            return hbm(8 * (bp.nAB + 2 * bp.nL + 2 * bp.nLx + 3 * n + n_obs), "AB + 2 (L + Lx) + 3 n + n_obs doubles per sample")
+            # (value slots: the physical ones -- slots with the same affine record are shared and mostly served by L2)
+            return hbm(8 * (eng.band_slots + 2 * bp.nL + 2 * bp.nLx + 3 * n + n_obs), "value slots + 2 (L + Lx) + 3 n + n_obs doubles per sample")
         # interpreter: lower bound -- L written once and read once, y / w, parameters; its operand re-fetches come on top
         return hbm(8 * (2 * plan.nnzL + 4 * n + pairs.xdim + n_obs), "lower bound: 2 nnz(L) + 4 n + xdim + n_obs doubles per sample")
     if dom == "rom_reduced_solve":
@@ -551,7 +552,7 @@ def roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl)
         return hbm(8 * (3 * npk + rp + r + n_obs), "lower bound: 3 packed triangles + B_r + w_r + qoi_r per sample")
     if dom == "fom_assemble":
         eng = solver._engine("field" if args.params == "field" else args.params)
-        nval = eng.band.nAB if eng.band is not None else len(eng._streams["a_list"])
+        nval = eng.band_slots if eng.band is not None else len(eng._streams["a_list"])
         return hbm(8 * (nval + pairs.xdim), "value slots written + parameters read")
     if dom == "sampler_gemm_exp":
         return mfma(n * n, "n^2 (triangular half of the dense GEMM)")

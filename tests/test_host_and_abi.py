@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in finrom.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib.finrom_version.restype = ctypes.c_int
-    assert lib.finrom_version() == 7
+    assert lib.finrom_version() == 8
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -321,3 +321,27 @@ def test_function_writes_invalidate_the_cached_observables(spaces):
     f = Function(V); f._qoi = np.arange(9.0)
     _ = f.vector()[:]; _ = f.vector().get_local()            # reads keep it
     assert f._qoi is not None
+
+
+def test_band_value_slots_are_shared_only_when_their_records_are_equal(spaces):
+    """bandplan.compact_slots: logical value slots with the same affine record share a physical slot (370 instead of 4887 for
+    the five fin conductivities at m = 12), the slots the fins write to stay private, and expanding the physical values
+    through the map reproduces every logical value exactly."""
+    import scipy.sparse as sp
+    ops = spaces(12).operators()
+    bp = ops.band_plan()
+    W = sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9 @ ops.E59))
+    c0, ptr, idx, w = bp.ab_table(ops.robin_vals, W)
+    abmap, c0p, ptrp, idxp, wp = bp.compact_slots(c0, ptr, idx, w)
+    assert len(c0p) < 600 < bp.nAB and abmap.max() == len(c0p) - 1
+    x = np.random.default_rng(0).uniform(0.1, 10.0, 5)
+    val = lambda c, p_, i_, w_, e: c[e] + (w_[p_[e]:p_[e + 1]] * x[i_[p_[e]:p_[e + 1]]]).sum()
+    phys = np.array([val(c0p, ptrp, idxp, wp, e) for e in range(len(c0p))])
+    logical = np.array([val(c0, ptr, idx, w, e) for e in range(bp.nAB)])
+    assert np.array_equal(phys[abmap], logical)
+    targets = [off for tg in bp.schur_target for _, _, off in tg]
+    assert len(set(abmap[targets].tolist())) == len(targets)                      # private
+    shared = np.bincount(abmap)
+    assert all(shared[abmap[t]] == 1 for t in targets)
+    Wf = ops.W_field                                                              # a nodal field: hardly any duplicates
+    assert len(bp.compact_slots(*bp.ab_table(ops.robin_vals, Wf))[1]) > 0.9 * 3 * bp.G
