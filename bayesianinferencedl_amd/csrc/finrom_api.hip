@@ -721,6 +721,18 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
     }
     flush();
     std::stable_sort(ksteps.begin(), ksteps.end(), [](const KStep& x, const KStep& y) { return x.pat.size() > y.pat.size(); });
+    // every term-count group gets an even number of k-steps (a k-step of zero rows pads it): the multi-wave main loop is
+    // unrolled twice and specialised by term count, so that its phases start at even k-steps
+    for (size_t k = 0; k < ksteps.size();) {
+      size_t k1 = k;
+      while (k1 < ksteps.size() && ksteps[k1].pat.size() == ksteps[k].pat.size()) ++k1;
+      if ((k1 - k) % 2) { ksteps.insert(ksteps.begin() + k1, KStep{ksteps[k].pat, {-1, -1, -1, -1}}); ++k1; }
+      k = k1;
+    }
+    for (int t = 0; t < 4; ++t) {
+      d.uend[t] = 0;
+      for (const KStep& ks : ksteps) if ((int)ks.pat.size() > t) ++d.uend[t];
+    }
     int uslots = 0;
     for (size_t k = 0; k < ksteps.size(); ++k) {
       const int nt = (int)ksteps[k].pat.size();
@@ -745,7 +757,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
       }
       uslots += nt;
     }
-    // per-k-step records for the interleaved main loop: {first slot, term count, -, -, theta index of slots 0..3}; four padding
+    // per-k-step records for the interleaved main loop: {first slot, term count, -, -, theta index of slots 0..3}; eight padding
     // k-steps point at the zero slots behind the table
     d.nku = (int)ksteps.size();
     {
@@ -757,7 +769,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
         kmeta.insert(kmeta.end(), rec, rec + 8);
         sl += nt;
       }
-      for (int k = 0; k < 4; ++k) { int rec[8] = {uslots, 1, 0, 0, 0, 0, 0, 0}; kmeta.insert(kmeta.end(), rec, rec + 8); }
+      for (int k = 0; k < 8; ++k) { int rec[8] = {uslots, 1, 0, 0, 0, 0, 0, 0}; kmeta.insert(kmeta.end(), rec, rec + 8); }
     }
     tvu.resize(tvu.size() + (size_t)4 * 4 * rp, 0.0);       // one k-step of padding for the prefetch
     kpat.resize(kpat.size() + 16, 0);                        // the scalar pipeline reads up to two k-steps ahead
@@ -939,9 +951,13 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
     // as well: no packed factor in memory, no second kernel
     if (factor && d.NB <= 5 && A_r == nullptr && B_r == nullptr && getenv("FINROM_NO_FUSED_SOLVE") == nullptr &&
         getenv("FINROM_PROJ_LDS") == nullptr) factor = 2;
+    // wider bases, only the reduced QoI wanted (the sample-pair path): factorisation and QoI stay in the registers of the
+    // projection kernel's waves (fused_solve_mw); A_r never reaches memory
+    if (d.NB > 6 && want_factor && h->projection == FINROM_PROJECTION_DIRECT && A_r == nullptr && B_r == nullptr && w_r == nullptr &&
+        qoi_r != nullptr && d.n_obs + 1 <= 16 * 3 && getenv("FINROM_NO_FUSED_SOLVE") == nullptr) factor = 3;
     if ((rc = rom_project(h, theta + s0 * d.P, Sc, factor, info ? info + s0 : nullptr, st,
                           w_r ? w_r + s0 * d.r : nullptr, qoi_r ? qoi_r + s0 * d.n_obs : nullptr))) return rc;
-    if (factor == 2) continue;
+    if (factor >= 2) continue;
     int factored = factor;
     if (want_factor && d.NB > 6) {                                     // wider bases: blocked MFMA Cholesky kernel
       if ((rc = launch_rom_chol_blocked(d, (double*)h->Ar.p, Sc, info ? info + s0 : nullptr, st))) return rc;

@@ -177,8 +177,10 @@ struct RomDev {
   const double* tvu;                    // [(nuslots + 4) * 4 * rp]
   const int* kpat;                      // [nuslots + 16] theta index of each slot (0 = the constant 1)
   int tvu_bytes;
-  int nku;                              // number of pattern-uniform k-steps
-  const int* kmeta;                     // [(nku + 4) * 8] per k-step: first slot, term count, 2 x padding, theta indices of its 4 slots
+  int nku;                              // number of pattern-uniform k-steps (even; sorted by term count, descending; every
+                                        // term-count group holds an even number of k-steps, padded with a zero k-step)
+  int uend[4];                          // uend[t] = number of k-steps with more than t terms (uend[0] = nku)
+  const int* kmeta;                     // [(nku + 8) * 8] per k-step: first slot, term count, 2 x padding, theta indices of its 4 slots
   const double* tv;                     // [(nslots + 4) * 4 * rp]  padded r-vectors, slot-major
   const int* pidx;                      // [(nslots + 4) * 4]       theta index of each r-vector (0 = constant 1)
   // rows with a non-zero load F (root nodes), same slot format with a runtime term count

@@ -133,7 +133,7 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
 }
 
 template <int NB, int NW>
-__global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NB <= 5 ? 2 : 1)) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+__global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, 2) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                        int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
                                                        const int* __restrict__ kpat) {
@@ -321,7 +321,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
       return launch_rom_proj_single(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, cu_ticket);
     FR_CASE(6, 1)
     FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
-    FR_CASE(10, 4) FR_CASE(11, 4) FR_CASE(12, 4) FR_CASE(13, 8)   // r > 192: 8 waves per sample so that a wave's tiles fit architectural VGPRs
+    FR_CASE(10, 8) FR_CASE(11, 8) FR_CASE(12, 8) FR_CASE(13, 8)   // r > 144: 8 waves per sample so that a wave's tiles (and its share of the fused epilogue's extra columns) fit 256 VGPRs
     default:
       set_error("rom_proj: basis size " + std::to_string(p.r) + " > 208 not supported");
       return FINROM_ERR_UNSUPPORTED;

@@ -341,6 +341,300 @@ __device__ __forceinline__ void proj_main_uniform(const RomDev& p, const int* __
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Main loop of the multi-wave kernels (NW waves = one workgroup = one sample, r > 96) on the same pattern-uniform tables.
+// Wave W owns the blocks b = W, W + NW, .. of the slab (builds them: 1/NW of the table loads and multiply-adds) and the
+// tiles idx = W, W + NW, .. of the block triangle; the slab travels through LDS.  Same interleaving as above -- everything
+// that is not an MFMA sits in the gaps between this wave's own MFMAs -- with the exchange software-pipelined over THREE LDS
+// slab buffers so that one barrier per k-step is enough and nobody waits for a write it needs at once:
+//   iteration ks:  MFMAs on vc (= slab ks, in registers), and in the gaps
+//     gap 0   vn <- LDS slab ks + 1                     (complete since the barrier that ended iteration ks - 1)
+//     gap 1   own blocks of slab ks + 2 = sum_t theta_t raw_t  -> LDS buffer (ks + 2) % 3   (last read in iteration ks - 2)
+//     gap 2,3 raw[ks & 1] <- table rows of k-step ks + 4        (two k-steps to land: a k-step here is only ~9 MFMAs long)
+//     gap 4   scalar loads: thetas of k-step ks + 4, record of k-step ks + 5
+//   s_waitcnt lgkmcnt(0); s_barrier      (NOT __syncthreads(): that would also wait for the table loads just issued)
+// ---------------------------------------------------------------------------------------
+template <int NB, int NW, int W>
+__device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int* __restrict__ kmeta_g,
+                                                     const double* __restrict__ theta_g, int q, int c, int lane, double* slab,
+                                                     d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
+  constexpr int NT = NB * (NB + 1) / 2;
+  constexpr int MINE = (NT - W + NW - 1) / NW;           // tiles of this wave
+  constexpr int NOWN = (NB - W + NW - 1) / NW;           // slab blocks of this wave
+  static_assert(MINE >= 5, "five gaps are used");
+  typedef const i4 __attribute__((address_space(4)))* c_i4_p;
+  const c_i4_p kmeta = (c_i4_p)(unsigned long long)kmeta_g;
+  const c_f64_p theta_s = (c_f64_p)(unsigned long long)theta_g;
+  const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.tvu), 0, p.tvu_bytes, 0x00020000);
+  const int voff = (q * p.rp + c + 16 * W) * 8;
+  const int rowb = 4 * p.rp * 8;
+  auto theta_of = [&](int pp) -> double { return pp == 0 ? 1.0 : theta_s[pp - 1]; };
+  auto thetas = [&](double (&th)[ROM_MAX_NT], const i4& k) { sfor<0, ROM_MAX_NT>([&](auto tc) { th[decltype(tc)::value] = theta_of(k[decltype(tc)::value]); }); };
+  auto load_raw = [&](double (&raw)[ROM_MAX_NT][NOWN], auto tc, int slot, int nt) {
+    constexpr int t = decltype(tc)::value;
+    if (t < nt) {
+      asm volatile("" ::: "memory");
+      sfor<0, NOWN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        raw[t][j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * NW * j, (slot + t) * rowb, 0));
+      });
+    }
+  };
+  auto load_all = [&](double (&raw)[ROM_MAX_NT][NOWN], const i4& m) { sfor<0, ROM_MAX_NT>([&](auto tc) { load_raw(raw, tc, m[0], m[1]); }); };
+  // own blocks of one slab -> LDS buffer at (double) offset o
+  auto build_store = [&](const double (&raw)[ROM_MAX_NT][NOWN], const double (&th)[ROM_MAX_NT], int nt, int o) {
+    double own[NOWN];
+    sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = th[0] * raw[0][j]; });
+    sfor<1, ROM_MAX_NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if (t < nt) {
+        asm volatile("" ::: "memory");
+        sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = fma(th[t], raw[t][j], own[j]); });
+      }
+    });
+    sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; slab[o + (W + j * NW) * 64 + lane] = own[j]; });
+  };
+  auto read_slab = [&](double (&v)[NB], int o) { sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; v[b] = slab[o + b * 64 + lane]; }); };
+  auto exchange = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  double rawa[ROM_MAX_NT][NOWN], rawb[ROM_MAX_NT][NOWN], thB[ROM_MAX_NT], thN[ROM_MAX_NT], va[NB], vb[NB];
+  sfor<0, ROM_MAX_NT>([&](auto tc) { sfor<0, NOWN>([&](auto jc) { rawa[decltype(tc)::value][decltype(jc)::value] = 0.0; rawb[decltype(tc)::value][decltype(jc)::value] = 0.0; }); });
+  // prologue: slabs 0 and 1 into LDS, va <- slab 0, raw buffers <- k-steps 2 and 3, scalars up to k-step 4
+  constexpr int SL = NB * 64;
+  int o0 = 0, o1 = SL, o2 = 2 * SL;
+  {
+    const i4 m0 = kmeta[0], k0 = kmeta[1], m1 = kmeta[2], k1 = kmeta[3];
+    load_all(rawa, m0); load_all(rawb, m1);
+    thetas(thB, k0); thetas(thN, k1);
+    build_store(rawa, thB, m0[1], o0);
+    build_store(rawb, thN, m1[1], o1);
+  }
+  const i4 m2 = kmeta[4], k2 = kmeta[5], m3 = kmeta[6], k3 = kmeta[7];
+  load_all(rawa, m2); load_all(rawb, m3);
+  thetas(thB, k2); thetas(thN, k3);
+  i4 m4 = kmeta[8], k4 = kmeta[9];
+  exchange();
+  read_slab(va, o0);
+
+  // One iteration, specialised by the term count NTS of the slab it BUILDS (k-step ks + 2).  Term counts fall along the
+  // table, so the k-step it loads (ks + 4) has at most NTS terms: NTS rows are fetched (a fixed number of loads in flight:
+  // the compiler can then wait for exactly the older buffer instead of vmcnt(0)), the build two iterations later uses its own.
+  auto step = [&](auto ntc, double (&vc)[NB], double (&vn)[NB], double (&raw)[ROM_MAX_NT][NOWN], int ks) {
+    constexpr int NTS = decltype(ntc)::value;
+    double thNN[ROM_MAX_NT];
+    i4 m5, k5;
+    sfor<0, MINE>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int idx = W + i * NW;
+      constexpr int ti = tile_ti<NB>(idx), tj = tile_tj<NB>(idx);
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(vc[ti]), "v"(vc[tj]));
+      if constexpr (i == 0) read_slab(vn, o1);
+      if constexpr (i == 1) {
+        double own[NOWN];
+        sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = thB[0] * raw[0][j]; });
+        sfor<1, NTS>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = fma(thB[t], raw[t][j], own[j]); });
+        });
+        sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; slab[o2 + (W + j * NW) * 64 + lane] = own[j]; });
+      }
+      if constexpr (i == 2 || i == 3) {
+        sfor<(i - 2) * 2, (i - 2) * 2 + 2>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          if constexpr (t < NTS)
+            sfor<0, NOWN>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+              raw[t][j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * NW * j, (m4[0] + t) * rowb, 0));
+            });
+        });
+      }
+      if constexpr (i == 4) { thetas(thNN, k4); m5 = kmeta[2 * (ks + 5)]; k5 = kmeta[2 * (ks + 5) + 1]; }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, ROM_MAX_NT>([&](auto tc) { constexpr int t = decltype(tc)::value; thB[t] = thN[t]; thN[t] = thNN[t]; });
+    m4 = m5; k4 = k5;
+    const int o = o0; o0 = o1; o1 = o2; o2 = o;
+    exchange();
+  };
+  // iterations [0, uend[3] - 2) build four-term slabs, then three-, two-, one-term ones up to nku (ends are even)
+  int ks = 0;
+  sfor<0, ROM_MAX_NT>([&](auto pc) {
+    constexpr int NTS = ROM_MAX_NT - decltype(pc)::value;
+    const int end = NTS == 1 ? p.nku : p.uend[NTS - 1] - 2;
+#pragma unroll 1
+    for (; ks < end; ks += 2) {
+      step(std::integral_constant<int, NTS>{}, va, vb, rawa, ks);
+      step(std::integral_constant<int, NTS>{}, vb, va, rawb, ks + 1);
+    }
+  });
+}
+
+// ---------------------------------------------------------------------------------------
+// Factorisation + reduced QoI for the multi-wave kernels WITHOUT leaving the registers (factor == 3: only qoi_r is wanted).
+// The block triangle of A_r stays where the main loop accumulated it -- tile idx in wave idx % NW -- and LDS only carries what
+// one block row hands to the others.  Right-looking by block rows kb:
+//   (a) the owner of the diagonal tile factors it with the 16 row operations of chol_tiles, applied to [A_kk | I]:
+//       that leaves U_kk and M = U_kk^-T (M A_kk = U_kk); M goes to LDS (transposed: the layout of an MFMA A operand);
+//   (b) every tile right of it becomes U(kb, tj) = M A(kb, tj): 4 MFMAs instead of 16 shuffle steps; result -> LDS panel;
+//   (c) every wave updates its own tiles T(ti, tj) -= U(kb, ti)^T U(kb, tj), operands straight from the LDS panel (an
+//       accumulator tile in the C/D layout IS a valid A / B operand of the next product, register g = k-step g).
+// Two barriers per block row.  The substitutions ride along as ROM_NXM extra tile columns G = [B_r | (B_obs Phi)^T]
+// (1 + n_obs <= 16 ROM_NXM columns): the same operations turn them into Z = U^-T G, and
+//   qoi_r = (B_obs Phi) U^-1 U^-T B_r = Z[:, 1:]^T Z[:, 0]      (rom :304, :323-333)
+// needs no backward substitution, so U is never needed again: nothing but qoi_r leaves the kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int ROM_NXM = 3;
+template <int NB> constexpr int tidx(int ti, int tj) { return ti * NB - (ti * (ti - 1)) / 2 + (tj - ti); }
+template <int NB> constexpr int fused_mw_lds_doubles() { return 256 + (NB + ROM_NXM) * 256 + 2 * 16 * NB + NB * 16 * ROM_NXM + 2; }
+
+template <int NB, int NW, int W>
+__device__ __forceinline__ void fused_solve_mw(const RomDev& p, d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW], const double (&bacc)[NB],
+                                               int64_t s, int lane, double* lds, double* __restrict__ qoi_r, int* __restrict__ info) {
+  constexpr int NT = NB * (NB + 1) / 2, MINE = (NT - W + NW - 1) / NW;
+  constexpr int NE = NB * ROM_NXM, EMINE = (NE - W + NW - 1) / NW;
+  const int q = lane >> 4, c = lane & 15;
+  double* minvT = lds;
+  double* panel = lds + 256;
+  double* bvec = panel + (NB + ROM_NXM) * 256;
+  double* ybuf = bvec + 16 * NB;
+  double* qpart = ybuf + 16 * NB;
+  int* flag = (int*)(qpart + NB * 16 * ROM_NXM);
+  const int nx = (p.n_obs + 1 + 15) / 16;
+  if constexpr (W == 0) {
+    if (q == 0) sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; bvec[16 * b + c] = bacc[b]; });
+    if (lane == 0) *flag = 0;
+  }
+  __syncthreads();
+  d4 ext[EMINE];
+  sfor<0, EMINE>([&](auto ec) {
+    constexpr int e = decltype(ec)::value, eidx = W + e * NW, kb = eidx / ROM_NXM, x = eidx % ROM_NXM;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + q + 4 * g, col = 16 * x + c;
+      double v = 0.0;
+      if (x < nx) {
+        if (col == 0) v = bvec[row];
+        else if (col <= p.n_obs && row < p.r) v = p.obs_phi[(col - 1) * p.r + row];
+      }
+      ext[e][g] = v;
+    }
+  });
+  // padding rows / columns (>= r) of psi^T psi are zero: unit diagonal
+  sfor<0, MINE>([&](auto ic) {
+    constexpr int i = decltype(ic)::value, idx = W + i * NW, ti = tile_ti<NB>(idx), tj = tile_tj<NB>(idx);
+    if constexpr (ti == tj) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (q + 4 * g == c && 16 * ti + c >= p.r) acc[i][g] = 1.0;
+    }
+  });
+  sfor<0, NB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+    constexpr int dI = tidx<NB>(kb, kb);
+    if constexpr (dI % NW == W) {                          // (a)
+      d4& D = acc[dI / NW];
+      double E[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) E[g] = (q + 4 * g == c) ? 1.0 : 0.0;
+      int bad = 0;
+#pragma unroll
+      for (int gs = 0; gs < 4; ++gs)
+#pragma unroll 1
+        for (int qs = 0; qs < 4; ++qs) {
+          const int st = 4 * gs + qs;
+          const double piv = read_lane_f64(D[gs], qs * 16 + st);
+          bad |= !(piv > 0.0);
+          double rinv = __builtin_amdgcn_rsq(piv);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+          const double sc = (q == qs) ? rinv : 1.0;
+          D[gs] *= sc; E[gs] *= sc;
+          const double rvD = __shfl(D[gs], qs * 16 + c), rvE = __shfl(E[gs], qs * 16 + c);
+          double m[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const double v = __shfl(D[gs], qs * 16 + ((q + 4 * g) & 15));
+            m[g] = (q + 4 * g > st) ? v : 0.0;                            // U[st][row of this lane], rows below the pivot only
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) { D[g] = fma(-m[g], rvD, D[g]); E[g] = fma(-m[g], rvE, E[g]); }
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) minvT[c * 16 + q + 4 * g] = E[g];        // E = M[row q + 4g][col c]
+      if (bad && lane == 0) { atomicOr(flag, 1); if (info != nullptr) atomicOr(&info[s], 2); }
+    }
+    __syncthreads();
+    {                                                     // (b)
+      double Am[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Am[g] = minvT[(q + 4 * g) * 16 + c];     // A operand of k-step g: M[m = c][k = q + 4g]
+      auto solve_tile = [&](d4& T, int slot) {
+        d4 n = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) n = __builtin_amdgcn_mfma_f64_16x16x4f64(Am[g], T[g], n, 0, 0, 0);
+        T = n;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) panel[slot * 256 + g * 64 + lane] = n[g];
+      };
+      sfor<kb + 1, NB>([&](auto jc) {
+        constexpr int tj = decltype(jc)::value, I = tidx<NB>(kb, tj);
+        if constexpr (I % NW == W) solve_tile(acc[I / NW], tj);
+      });
+      sfor<0, ROM_NXM>([&](auto xc) {
+        constexpr int x = decltype(xc)::value, e = kb * ROM_NXM + x;
+        if constexpr (e % NW == W) { if (x < nx) solve_tile(ext[e / NW], NB + x); }
+      });
+    }
+    __syncthreads();
+    if constexpr (kb + 1 < NB) {                           // (c)
+      auto update = [&](d4& T, int sa, int sb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          T = __builtin_amdgcn_mfma_f64_16x16x4f64(-panel[sa * 256 + g * 64 + lane], panel[sb * 256 + g * 64 + lane], T, 0, 0, 0);
+      };
+      sfor<0, MINE>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, idx = W + i * NW, ti = tile_ti<NB>(idx), tj = tile_tj<NB>(idx);
+        if constexpr (ti > kb) update(acc[i], ti, tj);
+      });
+      sfor<0, EMINE>([&](auto ec) {
+        constexpr int e = decltype(ec)::value, eidx = W + e * NW, kbe = eidx / ROM_NXM, x = eidx % ROM_NXM;
+        if constexpr (kbe > kb) { if (x < nx) update(ext[e], kbe, NB + x); }
+      });
+    }
+  });
+  // y = Z[:, 0] -> LDS; per block row the partial sums of Z[:, col]^T y; summed over the block rows in a fixed order
+  sfor<0, EMINE>([&](auto ec) {
+    constexpr int e = decltype(ec)::value, eidx = W + e * NW, kb = eidx / ROM_NXM, x = eidx % ROM_NXM;
+    if constexpr (x == 0) {
+      if (c == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ybuf[16 * kb + q + 4 * g] = ext[e][g];
+      }
+    }
+  });
+  __syncthreads();
+  sfor<0, EMINE>([&](auto ec) {
+    constexpr int e = decltype(ec)::value, eidx = W + e * NW, kb = eidx / ROM_NXM, x = eidx % ROM_NXM;
+    double part = 0.0;
+    if (x < nx) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) part = fma(ext[e][g], ybuf[16 * kb + q + 4 * g], part);
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (q == 0) qpart[kb * (16 * ROM_NXM) + 16 * x + c] = part;
+  });
+  __syncthreads();
+  if constexpr (W == 0) {
+    if (qoi_r != nullptr && lane >= 1 && lane <= p.n_obs && lane < 16 * ROM_NXM) {
+      double d = 0.0;
+#pragma unroll
+      for (int kb = 0; kb < NB; ++kb) d += qpart[kb * (16 * ROM_NXM) + lane];
+      qoi_r[s * p.n_obs + lane - 1] = *flag ? __builtin_nan("") : d;
+    }
+  }
+}
+
 template <int NB, int NW, int W>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
@@ -356,51 +650,10 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
   const int rp_ld = p.clock_probe == 2 ? 0 : p.rp;      // FINROM_CLOCK_PROBE=2 (timing experiment, results are garbage): every
                                                        // table fetch hits the same four rows -> no L2 traffic, same instructions
   if constexpr (NW > 1) {
-    // The NW waves of a sample (= the workgroup) share the slab through LDS: wave W builds its own blocks from the tables
-    // (1/NW of the loads and multiply-adds: stand-alone, every wave rebuilding the whole slab saturates the CU's L1 path),
-    // writes them to slab[ks & 1], and after ONE barrier per k-step every wave reads the whole slab back for its tiles.
-    // Double-buffered: a wave can only be one barrier ahead, so the buffer it overwrites is no longer being read.
-    constexpr int NOWN = (NB - W + NW - 1) / NW;
-    double raw[ROM_MAX_NT][NOWN];
-    int pi[ROM_MAX_NT];
-    int ph = 0, par = 0;
-    while (ph < p.n_phases && p.phase_ks0[ph] >= p.phase_ks1[ph]) ++ph;
-    if (ph < p.n_phases) load_kstep_own<NB, NW, W>(p.tv, p.pidx, p.phase_slot0[ph], p.phase_nt[ph], p.rp, q, c, raw, pi);
-#pragma unroll 1
-    for (; ph < p.n_phases; ++ph) {
-      const int ks0 = p.phase_ks0[ph], ks1 = p.phase_ks1[ph], slot0 = p.phase_slot0[ph], nt = p.phase_nt[ph];
-      int nph = ph + 1;
-      while (nph < p.n_phases && p.phase_ks0[nph] >= p.phase_ks1[nph]) ++nph;
-      const int next_slot = nph < p.n_phases ? p.phase_slot0[nph] : slot0 + (ks1 - ks0) * nt;
-      const int next_nt = nph < p.n_phases ? p.phase_nt[nph] : 1;
-#pragma unroll 1
-      for (int ks = ks0; ks < ks1; ++ks) {
-        double own[NOWN];
-#pragma unroll
-        for (int j = 0; j < NOWN; ++j) own[j] = 0.0;
-        double thp[ROM_MAX_NT];
-#pragma unroll
-        for (int t = 0; t < ROM_MAX_NT; ++t) thp[t] = thw[pi[t]];      // four LDS reads in flight together
-#pragma unroll
-        for (int t = 0; t < ROM_MAX_NT; ++t) {
-          if (t < nt) {
-#pragma unroll
-            for (int j = 0; j < NOWN; ++j) own[j] = fma(thp[t], raw[t][j], own[j]);
-          }
-        }
-        double* buf = slab + par * (NB * 64);
-        par ^= 1;
-#pragma unroll
-        for (int j = 0; j < NOWN; ++j) buf[(W + j * NW) * 64 + lane] = own[j];
-        const bool last = ks + 1 == ks1;
-        load_kstep_own<NB, NW, W>(p.tv, p.pidx, last ? next_slot : slot0 + (ks + 1 - ks0) * nt, last ? next_nt : nt, p.rp, q, c, raw, pi);
-        __syncthreads();
-        double v[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) v[b] = buf[b * 64 + lane];
-        mfma_tiles<NB, NW, W>(v, acc);
-      }
-    }
+    // (round 1's loop -- per-lane theta indices, two slab buffers, __syncthreads() per k-step -- reached 0.50 of the MFMA peak
+    // at r = 120 where this one reaches 0.7; it is gone: its run-time indexing of the phase tables inside RomDev made hipcc keep a
+    // copy of the kernel arguments in scratch memory once the fused epilogue was added)
+    proj_main_uniform_mw<NB, NW, W>(p, kpat, theta_s, q, c, lane, slab, acc);
   } else if ((p.clock_probe & 15) != 3) {      // (bits 4 / 5: timing experiments without table loads / without scalar loads)
     proj_main_uniform<NB>(p, kpat, theta_s, q, c, acc);      // kpat = RomDev::kmeta as a kernel parameter  // (FINROM_CLOCK_PROBE=3: the per-lane-theta loop below, for A/B timing)
   } else
@@ -454,7 +707,8 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     }
   }
   // factor == 2: substitutions + QoI below, nothing stored but w_r, qoi_r (r <= 80)
-  const bool fused_solve = NW == 1 && NB <= 5 && factor == 2;
+  // factor == 3 (multi-wave kernels): factorisation + QoI in registers, nothing stored but qoi_r (fused_solve_mw)
+  const bool fused_solve = (NW == 1 && NB <= 5 && factor == 2) || (NW > 1 && factor == 3);
   // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15].
   // A_r is symmetric: tile (ti <= tj) element (row, col) is written as the LOWER element
   // (i = col, k = row) of the packed column-major lower triangle the solve kernel reads.
@@ -480,10 +734,10 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 
   // B_r = psi^T F (rom :297): F is non-zero on the root nodes only; their rows of psi are rebuilt
   // here (a handful of k-steps, VALU only) and reduced over the 4 row-groups by lane shuffles.
-  if (W == 0) {
-    double bacc[NB];
+  double bacc[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
+  for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
+  if (W == 0) {
 #pragma unroll 1
     for (int ks = 0; ks < p.rhs_nk; ++ks) {        // (not unrolled: the accumulator tiles are still live here)
       double v[NB];
@@ -533,6 +787,9 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
       }
     }
   }
+  if constexpr (NW > 1) {
+    if (factor == 3) fused_solve_mw<NB, NW, W>(p, acc, bacc, s, lane, slab, qoi_r, info);
+  }
 }
 
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
@@ -543,11 +800,11 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
                                                        int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
                                                        const int* __restrict__ kpat = nullptr) {
   constexpr int WPB = NW > 4 ? NW : 4;
-  static_assert(NW == 1 || NW >= 4, "a workgroup is one sample when its waves share the slab (uniform early exit, barriers)");
+  static_assert(NW == 1 || NW == 4 || NW == 8, "a workgroup is one sample when its waves share the slab (uniform early exit, barriers)");
   __shared__ double th[WPB][32];
-  __shared__ double slab_lds[NW > 1 ? 2 * NB * 64 : 1];
+  __shared__ double slab_lds[NW > 1 ? (3 * NB * 64 > fused_mw_lds_doubles<NB>() ? 3 * NB * 64 : fused_mw_lds_doubles<NB>()) : 1];
   double* slab = slab_lds;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: say so (scalar branches below)
   trace_begin(p.trace, blockIdx.x);
   const int64_t s = (int64_t)blockIdx.x * (WPB / NW) + wave / NW;
   if (s >= S) return;                       // no block-wide barrier below
@@ -555,33 +812,30 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
   if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
   __builtin_amdgcn_wave_barrier();
   const double* thw = th[wave];
+  // the sample index is wave-uniform: say so, so that the sample's parameters can be fetched with scalar loads
+  const unsigned long long ta = (unsigned long long)(theta + ((int64_t)blockIdx.x * (WPB / NW) + wave / NW) * p.P);
+  const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));     // provably in SGPRs
+  const double* theta_u = theta_s;
   if constexpr (NW == 1) {
-    // the sample index is wave-uniform: say so, so that the sample's parameters can be fetched with scalar loads
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const unsigned long long ta = (unsigned long long)(theta + ((int64_t)blockIdx.x * (WPB / NW) + wave_u) * p.P);
-    const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
-                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));     // provably in SGPRs
     rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r, nullptr, theta_s, kpat);
-  } else if constexpr (NW == 2) {
-    if (wave % 2 == 0) rom_proj_body<NB, 2, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab);
-    else rom_proj_body<NB, 2, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab);
   } else if constexpr (NW == 4) {
     switch (wave % 4) {
-      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
     }
   } else {
     switch (wave % 8) {
-      case 0: rom_proj_body<NB, 8, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 1: rom_proj_body<NB, 8, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 2: rom_proj_body<NB, 8, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 3: rom_proj_body<NB, 8, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 4: rom_proj_body<NB, 8, 4>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 5: rom_proj_body<NB, 8, 5>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      case 6: rom_proj_body<NB, 8, 6>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
-      default: rom_proj_body<NB, 8, 7>(p, thw, s, lane, Ar, Br, factor, info, nullptr, nullptr, slab); break;
+      case 0: rom_proj_body<NB, 8, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 1: rom_proj_body<NB, 8, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 2: rom_proj_body<NB, 8, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 3: rom_proj_body<NB, 8, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 4: rom_proj_body<NB, 8, 4>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 5: rom_proj_body<NB, 8, 5>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 6: rom_proj_body<NB, 8, 6>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      default: rom_proj_body<NB, 8, 7>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
     }
   }
   trace_end(p.trace, blockIdx.x);

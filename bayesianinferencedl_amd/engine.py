@@ -293,16 +293,20 @@ class RomEngine:
         check(lib().finrom_rom_create(C.byref(d), C.byref(h)), "finrom_rom_create")
         self._h = h
 
-    def solve(self, theta, want_state=False):
+    def solve(self, theta, want_state=False, want_w=True):
+        """want_w=False: only the reduced QoI comes back; bases wider than 96 then factor and solve inside the projection
+        kernel's registers (no A_r in memory)."""
         b = _Batch(theta, self.P)
         S, r = b.S, self.r
-        w_r, wp = b.new((S, r))
+        w_r, wp = b.new((S, r)) if want_w else (None, None)
         qoi, qp = b.new((S, self.n_obs))
         info, ip = b.new((S,), "i4")
         A_r, Ap = (b.new((S, r, r)) if want_state else (None, None))
         B_r, Bp = (b.new((S, r)) if want_state else (None, None))
         check(lib().finrom_rom_solve(self._h, b.ptr, S, wp, qp, Ap, Bp, ip, b.stream), "finrom_rom_solve")
-        out = {"w_r": b.out(w_r, (S, r)), "qoi_r": b.out(qoi, (S, self.n_obs)), "info": b.out(info, (S,), "i4")}
+        out = {"qoi_r": b.out(qoi, (S, self.n_obs)), "info": b.out(info, (S,), "i4")}
+        if want_w:
+            out["w_r"] = b.out(w_r, (S, r))
         if want_state:
             out["A_r"] = b.out(A_r, (S, r, r)); out["B_r"] = b.out(B_r, (S, r))
         return out

@@ -120,13 +120,13 @@ class AffineROMFin:
             return np.ascontiguousarray(K, dtype=np.float64) @ self.ops.S.T
         return self._avg(K)
 
-    def forward_nine_param_reduced_batch(self, theta, want_state=False):
-        """theta [S, 9] -> dict(w_r [S, r], qoi_r [S, n_obs], info [S] (, A_r, B_r))."""
-        return self._rom.solve(theta, want_state=want_state)
+    def forward_nine_param_reduced_batch(self, theta, want_state=False, want_w=True):
+        """theta [S, 9] -> dict(w_r [S, r] (want_w), qoi_r [S, n_obs], info [S] (, A_r, B_r))."""
+        return self._rom.solve(theta, want_state=want_state, want_w=want_w)
 
-    def forward_reduced_batch(self, K, want_state=False):
+    def forward_reduced_batch(self, K, want_state=False, want_w=True):
         """K [S, n] nodal fields -> theta = S k on the device -> reduced solve."""
-        return self._rom.solve(self.subfin_avg_batch(K), want_state=want_state)
+        return self._rom.solve(self.subfin_avg_batch(K), want_state=want_state, want_w=want_w)
 
     def forward_batch(self, K, want_w=True):
         """'Averaged FOM' (:237-258) for a batch of nodal fields."""

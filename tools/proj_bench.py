@@ -20,7 +20,7 @@ th = torch.from_numpy(rng.uniform(0.1, 10.0, (S, 9))).cuda()
 x5 = torch.from_numpy(rng.uniform(0.1, 10.0, (S, 5))).cuda()
 L = _ffi.lib()
 def run():
-    if what == "rom": return rom.forward_nine_param_reduced_batch(th)
+    if what == "rom": return rom.forward_nine_param_reduced_batch(th, want_w=os.environ.get("WANT_W", "0") == "1")
     return fin.forward_batch(x5, want_w=False, params="five")
 run(); torch.cuda.synchronize()
 L.finrom_profile_reset(); L.finrom_profile_enable(1)
