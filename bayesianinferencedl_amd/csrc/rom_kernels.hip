@@ -133,7 +133,7 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
 }
 
 template <int NB, int NW>
-__global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, 2) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+__global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NW == 4 && NB <= 8) ? 3 : 2) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                        int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
                                                        const int* __restrict__ kpat) {

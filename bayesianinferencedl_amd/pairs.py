@@ -28,16 +28,19 @@ class FinPairSolver:
         self.xdim = ops.n if lift is None else lift.shape[1]
         self.n_obs = self.solver.n_obs
 
-    def solve_pairs(self, X, want_w=False):
+    def solve_pairs(self, X, want_w=False, want_w_r=False):
+        """want_w / want_w_r: also return the FOM state / the reduced coefficients (the dataset loop keeps neither:
+        generate_fin_dataset.py:93-100 stores the parameters and qoi - qoi_r only; without w_r, bases wider than 96 factor and
+        solve inside the projection kernel's registers)."""
         fom = self.solver._engine("field" if self.params == "field" else self.params)
         rom = self.solver_r._rom
         b = _Batch(X, self.xdim)
         S = b.S
         qoi, qp = b.new((S, self.n_obs)); qoi_r, qrp = b.new((S, self.n_obs)); err, ep = b.new((S, self.n_obs))
-        w_r, wrp = b.new((S, rom.r)); theta, tp = b.new((S, rom.P)); info, ip = b.new((S,), "i4")
+        w_r, wrp = b.new((S, rom.r)) if want_w_r else (None, None); theta, tp = b.new((S, rom.P)); info, ip = b.new((S,), "i4")
         w, wp = (b.new((S, fom.n)) if want_w else (None, None))
         check(lib().finrom_solve_pairs(fom._h, rom._h, self._avg._S.ptr, b.ptr, S, qp, qrp, ep, wp, wrp, tp, ip, b.stream),
               "finrom_solve_pairs")
         return {"qoi": b.out(qoi, (S, self.n_obs)), "qoi_r": b.out(qoi_r, (S, self.n_obs)),
                 "err": b.out(err, (S, self.n_obs)), "w": b.out(w, (S, fom.n)) if want_w else None,
-                "w_r": b.out(w_r, (S, rom.r)), "theta": b.out(theta, (S, rom.P)), "info": b.out(info, (S,), "i4")}
+                "w_r": b.out(w_r, (S, rom.r)) if want_w_r else None, "theta": b.out(theta, (S, rom.P)), "info": b.out(info, (S,), "i4")}

@@ -526,12 +526,12 @@ def roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl)
 
     if dom == "rom_proj_mfma" and args.projection == "direct":
         # psi rows from the sparse tables, the symmetric half of psi^T psi, psi^T F on the ROOT rows only (F = 0 elsewhere) and --
-        # for r <= 80, where the reduced system is factored and solved in the same kernel -- r^3/3 + 2 r^2 + the reduced QoI
+        # where the reduced system is factored and solved in the same kernel (r <= 80, r > 96) -- r^3/3 + 2 r^2 + the reduced QoI
         nroot = int(np.count_nonzero(ops.F))
         f = fl["syrk_sym"] + 2 * solver_r._rom.nterms * r + 2 * nroot * r
-        if r <= 80:
+        if r <= 80 or r > 96:       # (96 < r: fused across the sample's waves when w_r is not asked for -- it is not, here)
             f += fl["reduced_solve"] + 2 * n_obs * r
-        return mfma(f, "n r (r+1) + 2 nterms r + 2 nroot r (+ r^3/3 + 2 r^2 + 2 n_obs r for r <= 80)")
+        return mfma(f, "n r (r+1) + 2 nterms r + 2 nroot r (+ r^3/3 + 2 r^2 + 2 n_obs r for r <= 80 and r > 96)")
     if dom == "rom_proj_mfma":
         # offline/online form: the block sum streams tile images out of L2; what HAS to cross HBM is theta in, w_r + qoi_r out
         return hbm(8 * (9 + r + n_obs), "compulsory bytes only (theta in; w_r, qoi_r out): the block images are L2 traffic")

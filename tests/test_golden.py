@@ -33,7 +33,7 @@ def test_gpu_reproduces_golden(spaces, kind, key, schedule, monkeypatch):
     if schedule == "interpreter":                  # the golden batches are small: also check the throughput schedule
         monkeypatch.setattr(E, "SMALL_MAX", 0)
     V = spaces(int(G["m"]))
-    res = FinPairSolver(V, G["phi"], params=kind).solve_pairs(G[key], want_w=True)
+    res = FinPairSolver(V, G["phi"], params=kind).solve_pairs(G[key], want_w=True, want_w_r=True)
     assert (res["info"] == 0).all()
     assert rel(res["w"], G[f"w_{kind}"]) < TOL
     assert rel(res["qoi"], G[f"qoi_{kind}"]) < TOL
