@@ -480,7 +480,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (a->nAB <= 0 || !a->abmap) return bad("nAB / abmap");
   for (int e = 0; e < 3 * G; ++e) if (a->abmap[e] < 0 || a->abmap[e] >= a->nAB) return bad("abmap");
   const int64_t nL = (int64_t)a->nfins * a->npf * a->NSF + (int64_t)a->npost * a->NSP;
-  const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n;
+  const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n + BAND_LDS_XSIZE;
   if (gsize * 512 >= (int64_t)1 << 31) { set_error("fom_set_band: workspace too long for 32-bit buffer offsets"); return FINROM_ERR_UNSUPPORTED; }
   if (a->ab_ptr[0] != 0 || a->ab_ptr[a->nAB] != a->nterms) return bad("ab_ptr");
   for (int e = 0; e < a->nAB; ++e) if (a->ab_ptr[e + 1] < a->ab_ptr[e]) return bad("ab_ptr");
@@ -510,7 +510,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   b.n = n; b.n_obs = d.n_obs; b.xdim = d.xdim; b.gsize = (int)gsize; b.nAB = a->nAB; b.nL = (int)nL; b.nLx = a->nLx;
   b.NSF = a->NSF; b.NSP = a->NSP; b.NX = a->NX; b.nfins = a->nfins; b.npf = a->npf; b.nif = a->nif; b.npost = a->npost;
   b.post_g0 = a->nfins * (a->npf + a->nif); b.post_e0 = a->nfins * a->npf; b.post_L0 = a->nfins * a->npf * a->NSF;
-  b.offL = a->nAB; b.offLx = a->nAB + (int)nL; b.offY = a->nAB + (int)nL + a->nLx;
+  b.offL = a->nAB; b.offLx = a->nAB + (int)nL; b.offY = a->nAB + (int)nL + a->nLx; b.offX = b.offY + n;
   // records of the assembly pre-pass (fom_assemble_kernel): every value slot, so that special slots start at zero
   std::vector<int> reci((size_t)a->nAB * 8, 0);
   std::vector<double> recd((size_t)a->nAB * 5, 0.0);
@@ -544,7 +544,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (!rc) rc = up(h->owned, &b.obs_idx, a->obs_idx, nobsnz);
   if (!rc) rc = up(h->owned, &b.obs_w, a->obs_w, nobsnz);
   if (rc) return rc;
-  b.on = 1;
+  b.on = getenv("FINROM_BAND_TIMING") != nullptr ? 2 : 1;      // 2: block 0 reports its phase clocks in sample 0's QoI (diagnostic)
   h->band = b;
   return 0;
 }

@@ -134,11 +134,12 @@ int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hip
 struct BandDev {
   int on = 0;
   int n, n_obs, xdim, gsize, nAB, nL, nLx, NSF, NSP, NX, nfins, npf, nif, npost, post_g0, post_e0, post_L0;
-  int offL, offLx, offY;
+  int offL, offLx, offY, offX;   // offX: the extras' state of the LDS-window variant (BAND_LDS_XSIZE doubles per lane)
   const int* abmap;          // [3 G] physical value slot of each entry of a segment node
   const double* Fg; const int* act; const int* lx_ptr; const int* ent_extra; const int* ecp_ptr; const int* ecp_slot; const int* ecp_off;
   const int* schur_off; const int* iface_elim; const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
 };
+constexpr int BAND_LDS_XSIZE = 256;
 bool band_supported(int NSF, int NSP, int NX);
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st);
 

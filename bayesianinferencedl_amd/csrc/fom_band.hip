@@ -195,6 +195,183 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
   }
 }
 
+// ---- forward sweep of the post with the window in LDS (meshes whose window does not fit the register file: m = 16, 20) -----------
+// Same algorithm and the same stored factor as band_sweep<NS, true, NXM>, different residence:
+//   window   NS (NS + 1) / 2 + NS doubles per lane in LDS (140 KB at m = 20: one wave per CU), addressed by POSITION -- entry
+//            (a, b) = nodes pivot + a, pivot + b -- instead of by renamed slot: the rank-1 update writes its result one
+//            position up the diagonal, W'(s-1, t-1) = W(s, t) - l_s l_t, so the window slides for free and every LDS address is
+//            an immediate while the loop over the pivots stays a run-time loop (the renamed form would need NS^3 / 2 unrolled
+//            multiply-adds: 43 KB of code at NS = 22).  In place is safe in ascending (s, t): the destination has been read.
+//   extras   (<= NXM far front members: NXM (NS + 3) + NXM (NXM - 1) / 2 doubles) do not fit next to it: they live in the
+//            wave's slice of the workspace (offX; L2-resident), indexed by renamed slot (node mod NS) with SGPR offsets, and are
+//            touched only by the pivots that have active extras (a quarter of them at m = 20), loads batched before the stores.
+template <int NS, int NXM>
+__device__ __forceinline__ void band_sweep_lds(const BandDev& p, const Io& io, double* __restrict__ wl, const double* __restrict__ Fg,
+                                               const int* __restrict__ abmap, const PostTables& T, int g0, int e0, int npiv, int ntot,
+                                               int L0, int& bad) {
+  constexpr int B = NS - 1, YO = NS * (NS + 1) / 2;
+  using L = XL<NS, NXM>;
+  const int offX = p.offX;
+  auto xld = [&](int idx) -> double { return io.ld(offX + idx); };
+  auto xst = [&](double v, int idx) { io.st(v, offX + idx); };
+  static_for<0, YO + NS>([&](auto i) { wl[decltype(i)::value * 64] = 0.0; });
+  for (int i = 0; i < L::SIZE; ++i) xst(0.0, i);
+
+  // node t (renamed slot u = t mod NS) enters the window at position P
+  // (ex, c0, c1, ft = ent_extra[t], ecp_ptr[t], ecp_ptr[t + 1], Fg[g0 + t]: fetched one pivot ahead by the main loop -- with one
+  // wave per CU nothing else hides the latency of a dependent scalar load)
+  auto enter = [&](auto pc, int t, int u, double ab0, double ab1, double ab2, int ex, int c0, int c1, double ft) {
+    constexpr int P = decltype(pc)::value;
+    double row[P + 1];
+    static_for<0, P>([&](auto kc) { row[decltype(kc)::value] = 0.0; });
+    double diag = 0.0, yv = 0.0;
+    static_for<0, NXM>([&](auto sc) { xst(0.0, L::X + decltype(sc)::value * NS + u); });
+    if (ex != 0) {                                       // the node was an extra: its state moves from the workspace into the window
+      const int sl = ex - 1;
+      static_for<0, P>([&](auto kc) {                    // position k holds node t - P + k
+        constexpr int k = decltype(kc)::value;
+        int sk = u - P + k; sk += sk < 0 ? NS : 0;
+        row[k] = xld(L::X + sl * NS + sk);
+      });
+      diag = xld(L::XD + sl); yv = xld(L::XY + sl);
+      double xo[NXM];
+      static_for<0, NXM>([&](auto oc) {                  // its couplings to the other extras become their window couplings
+        constexpr int o = decltype(oc)::value;
+        const int a = o > sl ? o : sl, b = o > sl ? sl : o;
+        xo[o] = (o != sl) ? xld(L::XX + a * (a - 1) / 2 + b) : 0.0;
+      });
+      static_for<0, NXM>([&](auto oc) {
+        constexpr int o = decltype(oc)::value;
+        if (o != sl) {
+          const int a = o > sl ? o : sl, b = o > sl ? sl : o;
+          xst(xo[o], L::X + o * NS + u);
+          xst(0.0, L::XX + a * (a - 1) / 2 + b);
+        }
+      });
+      for (int v = 0; v < NS; ++v) xst(0.0, L::X + sl * NS + v);
+      xst(0.0, L::XD + sl); xst(0.0, L::XY + sl);
+    }
+    if constexpr (P >= 1) row[P - 1] += ab1;             // previous node
+    if constexpr (P == B) row[0] += ab2;                 // the node B positions back
+    static_for<0, P>([&](auto kc) { constexpr int k = decltype(kc)::value; wl[tri(P, k) * 64] = row[k]; });
+    wl[tri(P, P) * 64] = diag + ab0;
+    wl[(YO + P) * 64] = yv + ft;
+    for (int c = c0; c < c1; ++c) {                      // long-range couplings of this node: to extras
+      const int idx = L::X + T.ecp_slot[c] * NS + u;
+      xst(xld(idx) + io.ld(T.ecp_off[c]), idx);
+    }
+  };
+
+  static_for<0, NS>([&](auto pc) {                       // prologue: the first NS nodes
+    constexpr int P = decltype(pc)::value;
+    if (P < ntot) {
+      const int g = 3 * (g0 + P);
+      enter(pc, P, P, io.ld(abmap[g]), io.ld(abmap[g + 1]), io.ld(abmap[g + 2]), T.ent_extra[P], T.ecp_ptr[P], T.ecp_ptr[P + 1], Fg[g0 + P]);
+    }
+  });
+  // Software pipeline of everything that comes from memory: the three matrix entries of the node that enters after pivot pp
+  // are requested two pivots ahead (their slot numbers three ahead), the table entries of pivot pp + 1 during pivot pp.
+  auto slots = [&](int q, int (&gi)[3]) {
+    if (q < npiv && q + NS < ntot) { const int g = 3 * (g0 + q + NS); gi[0] = abmap[g]; gi[1] = abmap[g + 1]; gi[2] = abmap[g + 2]; }
+  };
+  auto fetch = [&](int q, const int (&gi)[3], double (&ab)[3]) {
+    if (q < npiv && q + NS < ntot) { ab[0] = io.ld(gi[0]); ab[1] = io.ld(gi[1]); ab[2] = io.ld(gi[2]); }
+  };
+  struct Tab { int am, lx, ex, c0, c1; double ft; };
+  auto tables = [&](int q) -> Tab {
+    Tab r{0, 0, 0, 0, 0, 0.0};
+    if (q < npiv) {
+      r.am = T.act[q]; r.lx = T.lx_ptr[q];
+      if (q + NS < ntot) { const int t = q + NS; r.ex = T.ent_extra[t]; r.c0 = T.ecp_ptr[t]; r.c1 = T.ecp_ptr[t + 1]; r.ft = Fg[g0 + t]; }
+    }
+    return r;
+  };
+  double abA[3] = {0.0, 0.0, 0.0}, abB[3] = {0.0, 0.0, 0.0};
+  int giA[3] = {0, 0, 0}, giB[3] = {0, 0, 0}, giC[3] = {0, 0, 0};
+  slots(0, giA); slots(1, giB); slots(2, giC);
+  fetch(0, giA, abA); fetch(1, giB, abB);
+  Tab cur = tables(0);
+  int u = 0;
+#pragma unroll 1
+  for (int pp = 0; pp < npiv; ++pp) {
+    const Tab nxt = tables(pp + 1);                      // lands while this pivot's update runs
+    int giD[3] = {0, 0, 0};
+    slots(pp + 3, giD);
+    const double d = wl[0];
+    if (!(d > 0.0)) bad = 1;
+    double inv = __builtin_amdgcn_rsq(d);
+    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+    double l[NS];
+    static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; l[s_] = wl[tri(s_, 0) * 64] * inv; });
+    const int base = p.offL + L0 + pp * NS;
+    static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; io.template stk<s_ - 1>(l[s_], base); });
+    io.template stk<NS - 1>(inv, base);
+    const double yp = wl[YO * 64] * inv;
+    io.st(yp, p.offY + e0 + pp);
+    {
+      double yb[NS];
+      static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; yb[s_] = wl[(YO + s_) * 64]; });
+      static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; wl[(YO + s_ - 1) * 64] = fma(-l[s_], yp, yb[s_]); });
+    }
+    static_for<1, NS>([&](auto sc) {                     // the rank-1 update, written one position up the diagonal
+      constexpr int s_ = decltype(sc)::value;
+      static_for<1, s_ + 1>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        wl[tri(s_ - 1, t - 1) * 64] = fma(-l[s_], l[t], wl[tri(s_, t) * 64]);
+      });
+    });
+    // extras with a non-zero coupling to this pivot (a quarter of the pivots at m = 20): per extra, all loads of its row first,
+    // then the stores (a dependent load waits for the wave's older stores: ~4 us -- requesting the rows before the column of L
+    // is stored did not pay: 176 more live VGPRs for the same time)
+    const int am = cur.am;
+    if (am != 0) {
+      double le[NXM];
+      int k = p.offLx + cur.lx;
+      static_for<0, NXM>([&](auto sc) {
+        constexpr int sl = decltype(sc)::value;
+        le[sl] = 0.0;
+        if (am & (1 << sl)) {
+          double xv[NS];
+          static_for<0, NS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
+            xv[t] = xld(L::X + sl * NS + st_);
+          });
+          const double xy = xld(L::XY + sl), xd = xld(L::XD + sl);
+          const double v = xv[0] * inv;
+          le[sl] = v;
+          io.st(v, k); ++k;
+          xst(fma(-v, yp, xy), L::XY + sl);
+          xst(fma(-v, v, xd), L::XD + sl);
+          static_for<1, NS>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
+            xst(fma(-v, l[t], xv[t]), L::X + sl * NS + st_);
+          });
+        }
+      });
+      double xx[NXM * (NXM - 1) / 2];
+      static_for<0, NXM*(NXM - 1) / 2>([&](auto ic) { xx[decltype(ic)::value] = xld(L::XX + decltype(ic)::value); });
+      static_for<1, NXM>([&](auto ac) {
+        constexpr int a = decltype(ac)::value;
+        static_for<0, a>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          constexpr int i = a * (a - 1) / 2 + b;
+          xst(fma(-le[a], le[b], xx[i]), L::XX + i);
+        });
+      });
+    }
+    if (pp + NS < ntot) enter(std::integral_constant<int, B>{}, pp + NS, u, abA[0], abA[1], abA[2], cur.ex, cur.c0, cur.c1, cur.ft);
+    else { static_for<0, NS>([&](auto kc) { wl[tri(B, decltype(kc)::value) * 64] = 0.0; }); wl[(YO + B) * 64] = 0.0; }
+    abA[0] = abB[0]; abA[1] = abB[1]; abA[2] = abB[2];
+    fetch(pp + 2, giC, abB);
+    giC[0] = giD[0]; giC[1] = giD[1]; giC[2] = giD[2];
+    cur = nxt;
+    u = u + 1 == NS ? 0 : u + 1;
+  }
+}
+
 // ---- backward: L^T w = y over one segment (w overwrites y), pivots in reverse -------------------------------------------------
 template <int NS, bool POST, int NXM>
 __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, double* __restrict__ xs, const PostTables& T,
@@ -327,6 +504,104 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __re
   }
 }
 
+// the variant with the post's window in LDS (band_sweep_lds): one wave per CU
+template <int NSF, int NSP, int NXM>
+__global__ __launch_bounds__(64) void fom_band_lds_kernel(BandDev p, const int* __restrict__ abmap, const double* __restrict__ Fg,
+                                                          const int* __restrict__ act,
+                                                          const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra,
+                                                          const int* __restrict__ ecp_ptr, const int* __restrict__ ecp_slot,
+                                                          const int* __restrict__ ecp_off, const int* __restrict__ schur_off,
+                                                          const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr,
+                                                          const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                          double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,
+                                                          int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double xlds[];
+  const int lane = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;
+  Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000), lane * 8};
+  double* xs = xlds + lane;
+  const PostTables T{act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off};
+  int bad = 0;
+  constexpr int NIFT = (NSF - 1) * NSF / 2;
+  long long tk[6];
+  tk[0] = wall_clock64();
+  {
+    double win[NSF * (NSF + 1) / 2], yw[NSF];
+    for (int f = 0; f < p.nfins; ++f) {
+      const int npiv = p.npf, ntot = p.npf + p.nif;
+      band_sweep<NSF, false, NXM>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      int k = 0;
+      for (int t = 0; t < p.nif; ++t)
+        for (int s = 0; s <= t; ++s, ++k) {
+          const int a = (npiv + t) % NSF, b = (npiv + s) % NSF;
+          double v = 0.0;
+          static_for<0, NSF>([&](auto ac) {
+            static_for<0, decltype(ac)::value + 1>([&](auto bc) {
+              constexpr int ua = decltype(ac)::value, ub = decltype(bc)::value;
+              v = ((a == ua && b == ub) || (a == ub && b == ua)) ? win[tri(ua, ub)] : v;
+            });
+          });
+          const int off = schur_off[f * NIFT + k];
+          io.st(io.ld(off) + v, off);
+        }
+    }
+  }
+  tk[1] = wall_clock64();
+  band_sweep_lds<NSP, NXM>(p, io, xs, Fg, abmap, T, p.post_g0, p.post_e0, p.npost, p.npost, p.post_L0, bad);
+  tk[2] = wall_clock64();
+  // the window is dead: the backward sweep keeps the extras' solution values (XL::WX) in the same LDS
+  band_bsweep<NSP, true, NXM>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
+  tk[3] = wall_clock64();
+  for (int f = 0; f < p.nfins; ++f)
+    band_bsweep<NSF, false, NXM>(p, io, xs, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF);
+  tk[4] = wall_clock64();
+
+  const int64_t s = blk * 64 + lane;
+  const double nanv = __builtin_nan("");
+  if (bad) {
+    for (int i = 0; i < p.n; ++i) io.st(nanv, p.offY + i);
+    if (info != nullptr && s < S) atomicOr(&info[s], 1);
+  }
+  for (int o = 0; o < p.n_obs; ++o) {
+    double q0 = 0.0, q1 = 0.0;
+    const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
+    for (int t = t0; t < t1; t += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = io.ld(p.offY + obs_idx[(t + u < t1) ? t + u : t1 - 1]);
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        q0 = fma((t + u < t1) ? obs_w[t + u] : 0.0, v[u], q0);
+        q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
+      }
+    }
+    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q0 + q1;
+  }
+  if (p.on == 2 && s == 0)                               // FINROM_BAND_TIMING: 100 MHz ticks per phase
+    for (int i = 0; i < 4 && i < p.n_obs; ++i) qoi[i] = (double)(tk[i + 1] - tk[i]);
+}
+
+template <int NSF, int NSP>
+int launch_lds(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
+  constexpr int NXM = 8;
+  static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
+  constexpr size_t lds_w = (size_t)(NSP * (NSP + 1) / 2 + NSP) * 64 * sizeof(double);            // forward: window + y
+  constexpr size_t lds_b = (size_t)(XL<NSP, NXM>::WX + NXM) * 64 * sizeof(double);               // backward: XL::WX at its usual index
+  constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
+  static_assert(lds <= 160 * 1024, "LDS window");
+  static bool once = false;
+  if (!once) {
+    FR_HIP(hipFuncSetAttribute((const void*)fom_band_lds_kernel<NSF, NSP, NXM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((fom_band_lds_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.abmap, p.Fg, p.act, p.lx_ptr,
+                     p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx, p.obs_w,
+                     Gw, S, qoi, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int NSF, int NSP>
 int launch_t(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int NXM = 4;
@@ -341,7 +616,8 @@ int launch_t(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi,
 }  // namespace
 
 bool band_supported(int NSF, int NSP, int NX) {
-  return NX <= 4 && ((NSF == 3 && NSP == 6) || (NSF == 4 && NSP == 10) || (NSF == 5 && NSP == 14));
+  if (NX <= 4 && ((NSF == 3 && NSP == 6) || (NSF == 4 && NSP == 10) || (NSF == 5 && NSP == 14))) return true;      // window in registers
+  return NX <= 8 && ((NSF == 6 && NSP == 18) || (NSF == 7 && NSP == 22));                                           // window in LDS
 }
 
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
@@ -350,6 +626,8 @@ int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, doubl
   if (p.NSF == 3 && p.NSP == 6) return launch_t<3, 6>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 4 && p.NSP == 10) return launch_t<4, 10>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 5 && p.NSP == 14) return launch_t<5, 14>(p, Gw, nblk, S, qoi, info, st);
+  if (p.NSF == 6 && p.NSP == 18) return launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st);
+  if (p.NSF == 7 && p.NSP == 22) return launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st);
   set_error("fom band sweep: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }

@@ -16,7 +16,7 @@ def _rel(a, b):
     return np.max(np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1))
 
 
-@pytest.mark.parametrize("m", [4, 8, 12])
+@pytest.mark.parametrize("m", [4, 8, 12, 16, 20])      # 16, 20: the variant with the post's window in LDS
 def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
     import bayesianinferencedl_amd.engine as E
     from bayesianinferencedl_amd.fom.forward_solve import Fin
@@ -50,9 +50,10 @@ def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
             assert np.linalg.norm(res["qoi"][s] - q) < TOL * np.linalg.norm(q)
 
 
-def test_band_sweep_flags_indefinite_samples(spaces):
+@pytest.mark.parametrize("m", [12, 20])
+def test_band_sweep_flags_indefinite_samples(spaces, m):
     from bayesianinferencedl_amd.fom.forward_solve import Fin
-    V = spaces(12)
+    V = spaces(m)
     fin = Fin(V)
     rng = np.random.default_rng(3)
     X = rng.uniform(0.5, 2.0, (600, 9))
