@@ -31,6 +31,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
+constexpr __device__ __host__ int ent_s(int e) { int s = 1; while (e >= s) { e -= s; ++s; } return s; }      // row of packed entry e (rows from 1)
 constexpr __device__ __host__ int tri(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -314,16 +315,41 @@ __device__ __forceinline__ void band_sweep_lds(const BandDev& p, const Io& io, d
       static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; yb[s_] = wl[(YO + s_) * 64]; });
       static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; wl[(YO + s_ - 1) * 64] = fma(-l[s_], yp, yb[s_]); });
     }
-    static_for<1, NS>([&](auto sc) {                     // the rank-1 update, written one position up the diagonal
-      constexpr int s_ = decltype(sc)::value;
-      static_for<1, s_ + 1>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        wl[tri(s_ - 1, t - 1) * 64] = fma(-l[s_], l[t], wl[tri(s_, t) * 64]);
+    // the rank-1 update, written one position up the diagonal: entry e = (s - 1) s / 2 + t - 1 <-> (s, t), 1 <= t <= s <= B, in
+    // chunks of CH entries with the reads of chunk c + 1 issued before the arithmetic of chunk c (sched_barrier pins the phases):
+    // a lone wave has to keep the LDS queue full by itself (left to the compiler's schedule -- read, wait, fma, write per pair
+    // of entries, 1-3 reads in flight -- the pass was 7 % / 37 % slower at m = 20 / 16).  The pass is still the largest part of
+    // the sweep (5.2 of 8.5 ms per 16k samples at m = 20, measured with it skipped: ~30 cycles per entry): lgkmcnt counts to 15,
+    // so one wave has at most 15 LDS instructions in flight.  Next: two to four waves per 64 samples, the triangle split by
+    // DIAGONALS (the shift moves an entry along its diagonal, so the waves' in-place updates cannot collide)
+    {
+      constexpr int NE = B * (B + 1) / 2, CH = 24, NC = (NE + CH - 1) / CH;
+      double buf[2][CH];
+      auto rd = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        static_for<0, CH>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, e = c * CH + i;
+          if constexpr (e < NE) { constexpr int s_ = ent_s(e), t = e - (s_ - 1) * s_ / 2 + 1; buf[c & 1][i] = wl[tri(s_, t) * 64]; }
+        });
+      };
+      rd(std::integral_constant<int, 0>{});
+      static_for<0, NC>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        if constexpr (c + 1 < NC) rd(std::integral_constant<int, c + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, CH>([&](auto ic) {
+          constexpr int i = decltype(ic)::value, e = c * CH + i;
+          if constexpr (e < NE) {
+            constexpr int s_ = ent_s(e), t = e - (s_ - 1) * s_ / 2 + 1;
+            wl[tri(s_ - 1, t - 1) * 64] = fma(-l[s_], l[t], buf[c & 1][i]);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
       });
-    });
-    // extras with a non-zero coupling to this pivot (a quarter of the pivots at m = 20): per extra, all loads of its row first,
-    // then the stores (a dependent load waits for the wave's older stores: ~4 us -- requesting the rows before the column of L
-    // is stored did not pay: 176 more live VGPRs for the same time)
+    }
+    // extras with a non-zero coupling to this pivot (a quarter of the pivots at m = 20, four of them on average): per extra, all
+    // loads of its row first, then the stores.  (Measured with the block skipped: 1.3 of the sweep's 8.5 ms per 16k samples at
+    // m = 20; requesting the rows of four extras together, or before the column of L is stored, was slower: 176 more live VGPRs.)
     const int am = cur.am;
     if (am != 0) {
       double le[NXM];
@@ -578,7 +604,7 @@ __global__ __launch_bounds__(64) void fom_band_lds_kernel(BandDev p, const int* 
     }
     if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q0 + q1;
   }
-  if (p.on == 2 && s == 0)                               // FINROM_BAND_TIMING: 100 MHz ticks per phase
+  if ((p.on & 2) && s == 0)                               // FINROM_BAND_TIMING: 100 MHz ticks per phase
     for (int i = 0; i < 4 && i < p.n_obs; ++i) qoi[i] = (double)(tk[i + 1] - tk[i]);
 }
 
