@@ -400,7 +400,8 @@ def run_hmc(args, rank, local_rank, world):
     K0 = np.stack([np.exp(0.1 * np.random.default_rng(6 + c).standard_normal(V.dim())) for c in mine]) if mine else np.zeros((0, V.dim()))
     f = hmc.romml_value_and_grad(solver_r)
     L = 10
-    n_evals = 1 + args.steps // L * L                       # evaluation 0 (the start point) + whole trajectories
+    steps = args.steps if args.steps >= L else 2000         # (a step = one evaluation here; fewer than one trajectory: the default length)
+    n_evals = 1 + steps // L * L                            # evaluation 0 (the start point) + whole trajectories
 
     def fence():
         if world > 1:
