@@ -399,7 +399,213 @@ __device__ __forceinline__ void band_sweep_lds(const BandDev& p, const Io& io, d
 }
 
 // ---- backward: L^T w = y over one segment (w overwrites y), pivots in reverse -------------------------------------------------
-template <int NS, bool POST, int NXM>
+// ---- the same sweep by WV waves that share the 64 samples of a workgroup (fom_band_ldsw_kernel) ------------------------------------
+// One wave cannot keep more than 15 LDS instructions in flight (lgkmcnt), which left band_sweep_lds at ~30 cycles per updated
+// entry.  The update moves an entry ALONG ITS DIAGONAL (s, t) -> (s - 1, t - 1), so the triangle is split by diagonals d = s - t:
+// wave w owns the diagonals diag_owner(d) == w (snake order: equal entry counts), reads each of its diagonals in one burst and
+// writes it back one position up -- no two waves ever touch the same entry.  Every wave reads the pivot column and derives
+// 1/sqrt and the scaled column itself; the rest of a pivot is spread by role: wave ST stores the column of L and y, wave YU slides
+// the right-hand-side window, wave E (the last one) owns the extras' state, the entering node and its prefetch pipeline.
+// The entering node's row (window row B) and its right-hand side live in TWO buffers used alternately: wave E fills the buffer of
+// the next pivot while the others still read this pivot's row B, so ONE barrier per pivot is enough.
+// LDS (doubles per lane): rows 0..B-1 of the triangle | 2 x (row B: NS entries + y_B) | y_0..y_{B-1} | flag.
+template <int WV> constexpr int diag_owner(int d) { const int r = d % (2 * WV); return r < WV ? r : 2 * WV - 1 - r; }
+
+template <int NS, int NXM, int WV, int WVI>
+__device__ __forceinline__ void band_sweep_ldsw(const BandDev& p, const Io& io, double* __restrict__ wl, const double* __restrict__ Fg,
+                                                const int* __restrict__ abmap, const PostTables& T, int g0, int e0, int npiv, int ntot,
+                                                int L0, int& bad) {
+  constexpr int B = NS - 1, TB = B * (B + 1) / 2, RS = NS + 1, YO = TB + 2 * RS;
+  constexpr int ST = 0, YU = 1 % WV, E = WV - 1;
+  using L = XL<NS, NXM>;
+  const int offX = p.offX;
+  auto xld = [&](int idx) -> double { return io.ld(offX + idx); };
+  auto xst = [&](double v, int idx) { io.st(v, offX + idx); };
+  // window entry (a, b), a >= b, of the pivot whose row-B buffer is `par`
+  auto widx = [](int a, int b, int par) constexpr { return a < B ? tri(a, b) : TB + par * RS + b; };
+  auto barrier = [&]() { __syncthreads(); };
+
+  // node t (renamed slot u) enters at position P of the window whose row-B buffer is `par` (wave E only)
+  auto enter = [&](auto pc, auto parc, int t, int u, double ab0, double ab1, double ab2, int ex, int c0, int c1, double ft) {
+    constexpr int P = decltype(pc)::value, par = decltype(parc)::value;
+    double row[P + 1];
+    static_for<0, P>([&](auto kc) { row[decltype(kc)::value] = 0.0; });
+    double diag = 0.0, yv = 0.0;
+    static_for<0, NXM>([&](auto sc) { xst(0.0, L::X + decltype(sc)::value * NS + u); });
+    if (ex != 0) {
+      const int sl = ex - 1;
+      static_for<0, P>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        int sk = u - P + k; sk += sk < 0 ? NS : 0;
+        row[k] = xld(L::X + sl * NS + sk);
+      });
+      diag = xld(L::XD + sl); yv = xld(L::XY + sl);
+      double xo[NXM];
+      static_for<0, NXM>([&](auto oc) {
+        constexpr int o = decltype(oc)::value;
+        const int a = o > sl ? o : sl, b = o > sl ? sl : o;
+        xo[o] = (o != sl) ? xld(L::XX + a * (a - 1) / 2 + b) : 0.0;
+      });
+      static_for<0, NXM>([&](auto oc) {
+        constexpr int o = decltype(oc)::value;
+        if (o != sl) {
+          const int a = o > sl ? o : sl, b = o > sl ? sl : o;
+          xst(xo[o], L::X + o * NS + u);
+          xst(0.0, L::XX + a * (a - 1) / 2 + b);
+        }
+      });
+      for (int v = 0; v < NS; ++v) xst(0.0, L::X + sl * NS + v);
+      xst(0.0, L::XD + sl); xst(0.0, L::XY + sl);
+    }
+    if constexpr (P >= 1) row[P - 1] += ab1;
+    if constexpr (P == B) row[0] += ab2;
+    static_for<0, P>([&](auto kc) { constexpr int k = decltype(kc)::value; wl[widx(P, k, par) * 64] = row[k]; });
+    wl[widx(P, P, par) * 64] = diag + ab0;
+    if constexpr (P == B) wl[(TB + par * RS + NS) * 64] = yv + ft;
+    else wl[(YO + P) * 64] = yv + ft;
+    for (int c = c0; c < c1; ++c) {
+      const int idx = L::X + T.ecp_slot[c] * NS + u;
+      xst(xld(idx) + io.ld(T.ecp_off[c]), idx);
+    }
+  };
+
+  struct Tab { int am, lx, ex, c0, c1; double ft; };
+  auto tables = [&](int q) -> Tab {
+    Tab r{0, 0, 0, 0, 0, 0.0};
+    if (q < npiv) {
+      r.am = T.act[q]; r.lx = T.lx_ptr[q];
+      if (q + NS < ntot) { const int t = q + NS; r.ex = T.ent_extra[t]; r.c0 = T.ecp_ptr[t]; r.c1 = T.ecp_ptr[t + 1]; r.ft = Fg[g0 + t]; }
+    }
+    return r;
+  };
+  auto slots = [&](int q, int (&gi)[3]) {
+    if (q < npiv && q + NS < ntot) { const int g = 3 * (g0 + q + NS); gi[0] = abmap[g]; gi[1] = abmap[g + 1]; gi[2] = abmap[g + 2]; }
+  };
+  auto fetch = [&](int q, const int (&gi)[3], double (&ab)[3]) {
+    if (q < npiv && q + NS < ntot) { ab[0] = io.ld(gi[0]); ab[1] = io.ld(gi[1]); ab[2] = io.ld(gi[2]); }
+  };
+  double abA[3] = {0.0, 0.0, 0.0}, abB[3] = {0.0, 0.0, 0.0};
+  int giC[3] = {0, 0, 0};
+  Tab cur{0, 0, 0, 0, 0, 0.0};
+  if constexpr (WVI == E) {                              // prologue: empty window, the first NS nodes, the pipelines
+    static_for<0, YO + NS + 1>([&](auto i) { wl[decltype(i)::value * 64] = 0.0; });
+    for (int i = 0; i < L::SIZE; ++i) xst(0.0, i);
+    static_for<0, NS>([&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+      if (P < ntot) {
+        const int g = 3 * (g0 + P);
+        enter(pc, std::integral_constant<int, 0>{}, P, P, io.ld(abmap[g]), io.ld(abmap[g + 1]), io.ld(abmap[g + 2]), T.ent_extra[P],
+              T.ecp_ptr[P], T.ecp_ptr[P + 1], Fg[g0 + P]);
+      }
+    });
+    int giA[3] = {0, 0, 0}, giB[3] = {0, 0, 0};
+    slots(0, giA); slots(1, giB); slots(2, giC);
+    fetch(0, giA, abA); fetch(1, giB, abB);
+    cur = tables(0);
+  }
+  barrier();
+  int u = 0;
+  auto step = [&](auto parc, int pp) {
+    constexpr int par = decltype(parc)::value;
+    Tab nxt{0, 0, 0, 0, 0, 0.0};
+    int giD[3] = {0, 0, 0};
+    if constexpr (WVI == E) { nxt = tables(pp + 1); slots(pp + 3, giD); }
+    const double d = wl[0];
+    if (!(d > 0.0)) bad = 1;
+    double inv = __builtin_amdgcn_rsq(d);
+    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
+    double l[NS];
+    static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; l[s_] = wl[widx(s_, 0, par) * 64] * inv; });
+    const double yp = wl[YO * 64] * inv;
+    barrier();                                           // everybody has read the pivot column and y_0: the writes below may overwrite them
+    if constexpr (WVI == ST) {
+      const int base = p.offL + L0 + pp * NS;
+      static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; io.template stk<s_ - 1>(l[s_], base); });
+      io.template stk<NS - 1>(inv, base);
+      io.st(yp, p.offY + e0 + pp);
+    }
+    if constexpr (WVI == YU) {
+      double yb[NS];
+      static_for<1, NS>([&](auto sc) {
+        constexpr int s_ = decltype(sc)::value;
+        yb[s_] = s_ < B ? wl[(YO + s_) * 64] : wl[(TB + par * RS + NS) * 64];
+      });
+      static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; wl[(YO + s_ - 1) * 64] = fma(-l[s_], yp, yb[s_]); });
+    }
+    static_for<0, B>([&](auto dc) {                      // own diagonals: burst read, then write one position up
+      constexpr int dg = decltype(dc)::value;
+      if constexpr (diag_owner<WV>(dg) == WVI) {
+        double buf[B - dg];
+        static_for<dg + 1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; buf[s_ - dg - 1] = wl[widx(s_, s_ - dg, par) * 64]; });
+        static_for<dg + 1, NS>([&](auto sc) {
+          constexpr int s_ = decltype(sc)::value, t = s_ - dg;
+          wl[tri(s_ - 1, t - 1) * 64] = fma(-l[s_], l[t], buf[s_ - dg - 1]);
+        });
+      }
+    });
+    if constexpr (WVI == E) {
+      // extras with a non-zero coupling to this pivot, one after the other (requesting the rows of four of them together was not
+      // faster here either: 5.36 vs 5.24 ms)
+      const int am = cur.am;
+      if (am != 0) {
+        double le[NXM];
+        int k = p.offLx + cur.lx;
+        static_for<0, NXM>([&](auto sc) {
+          constexpr int sl = decltype(sc)::value;
+          le[sl] = 0.0;
+          if (am & (1 << sl)) {
+            double xv[NS];
+            static_for<0, NS>([&](auto tc) {
+              constexpr int t = decltype(tc)::value;
+              int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
+              xv[t] = xld(L::X + sl * NS + st_);
+            });
+            const double xy = xld(L::XY + sl), xd = xld(L::XD + sl);
+            const double v = xv[0] * inv;
+            le[sl] = v;
+            io.st(v, k); ++k;
+            xst(fma(-v, yp, xy), L::XY + sl);
+            xst(fma(-v, v, xd), L::XD + sl);
+            static_for<1, NS>([&](auto tc) {
+              constexpr int t = decltype(tc)::value;
+              int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
+              xst(fma(-v, l[t], xv[t]), L::X + sl * NS + st_);
+            });
+          }
+        });
+        double xx[NXM * (NXM - 1) / 2];
+        static_for<0, NXM*(NXM - 1) / 2>([&](auto ic) { xx[decltype(ic)::value] = xld(L::XX + decltype(ic)::value); });
+        static_for<1, NXM>([&](auto ac) {
+          constexpr int a = decltype(ac)::value;
+          static_for<0, a>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            constexpr int i = a * (a - 1) / 2 + b;
+            xst(fma(-le[a], le[b], xx[i]), L::XX + i);
+          });
+        });
+      }
+      if (pp + NS < ntot) enter(std::integral_constant<int, B>{}, std::integral_constant<int, 1 - par>{}, pp + NS, u, abA[0], abA[1], abA[2],
+                                cur.ex, cur.c0, cur.c1, cur.ft);
+      else static_for<0, RS>([&](auto kc) { wl[(TB + (1 - par) * RS + decltype(kc)::value) * 64] = 0.0; });
+      abA[0] = abB[0]; abA[1] = abB[1]; abA[2] = abB[2];
+      fetch(pp + 2, giC, abB);
+      giC[0] = giD[0]; giC[1] = giD[1]; giC[2] = giD[2];
+      cur = nxt;
+    }
+    u = u + 1 == NS ? 0 : u + 1;
+    barrier();
+  };
+#pragma unroll 1
+  for (int pp = 0; pp < npiv; pp += 2) {
+    step(std::integral_constant<int, 0>{}, pp);
+    if (pp + 1 < npiv) step(std::integral_constant<int, 1>{}, pp + 1);
+  }
+}
+
+constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+
+template <int NS, bool POST, int NXM, int RBX = 0>
 __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, double* __restrict__ xs, const PostTables& T,
                                             const int* __restrict__ iface, int e0, int npiv, int ntot, int L0) {
   using L = XL<NS, NXM>;
@@ -417,19 +623,37 @@ __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, doub
   // Software-pipelined like the forward sweep: the column of pivot v (NS values) and y_v were requested RB steps ago into ring
   // slot v mod RB (RB divides NS: compile-time slots); after using them the step requests pivot v - RB into the same slot.
   // RB columns in flight per wave (7 x 7.5 KB in the post at m = 12) is what keeps HBM busy with one wave per SIMD.
-  constexpr int RB = NS % 7 == 0 ? 7 : NS % 5 == 0 ? 5 : NS % 3 == 0 ? 3 : NS % 2 == 0 ? 2 : NS;
+  // (RBX: an explicit ring depth that need not divide NS -- the loop is then unrolled lcm(NS, RB) times)
+  constexpr int RB = RBX > 0 ? RBX : NS % 7 == 0 ? 7 : NS % 5 == 0 ? 5 : NS % 3 == 0 ? 3 : NS % 2 == 0 ? 2 : NS;
+  constexpr int U = NS / gcd_c(NS, RB) * RB;
+  // PFX (with RBX, the one-wave-per-CU callers): the pivot's table entries and its couplings to the extras travel with the
+  // column -- requested RB steps ahead, their own scalars one step before that -- instead of being fetched where they are used
+  constexpr bool PFX = POST && RBX > 0;
   double lb[RB][NS + 1];
+  double lxv[PFX ? RB : 1][NXM];
+  int am_r[PFX ? RB : 1], ex_r[PFX ? RB : 1];
   const int vtop = npiv - 1 + RB;
-  for (int p0 = vtop / NS * NS; p0 >= 0; p0 -= NS) {
-    static_for<0, NS>([&](auto rc) {
-      constexpr int u = NS - 1 - decltype(rc)::value;
-      constexpr int rs = u % RB;
-      const int v = p0 + u;
+  int am_q = 0, k_q = 0, ex_q = 0;                       // tables of pivot v - RB while step v runs (PFX)
+  auto tables = [&](int q) { if (q >= 0 && q < npiv) { am_q = T.act[q]; k_q = p.offLx + T.lx_ptr[q]; ex_q = T.ent_extra[q]; } else { am_q = 0; ex_q = 0; } };
+  if constexpr (PFX) tables(vtop - RB);                  // = npiv - 1, the pivot whose column the first executed step requests
+  for (int p0 = vtop / U * U; p0 >= 0; p0 -= U) {
+    static_for<0, U>([&](auto rc) {
+      constexpr int uu = U - 1 - decltype(rc)::value;
+      constexpr int u = uu % NS;
+      constexpr int rs = uu % RB;
+      const int v = p0 + uu;
       if (v <= vtop) {
         if (v < npiv) {
           double acc = lb[rs][NS];
           static_for<1, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; acc = fma(-lb[rs][s - 1], ww[(u + s) % NS], acc); });
-          if constexpr (POST) {
+          if constexpr (PFX) {
+            const int am = am_r[rs];
+            if (am != 0)
+              static_for<0, NXM>([&](auto sc) {
+                constexpr int sl = decltype(sc)::value;
+                if (am & (1 << sl)) acc = fma(-lxv[rs][sl], xs[(L::WX + sl) * 64], acc);
+              });
+          } else if constexpr (POST) {
             const int am = T.act[v];
             if (am != 0) {
               int k = p.offLx + T.lx_ptr[v];
@@ -443,7 +667,7 @@ __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, doub
           io.st(wv, p.offY + e0 + v);
           ww[u] = wv;
           if constexpr (POST) {
-            const int ex = T.ent_extra[v];
+            const int ex = PFX ? ex_r[rs] : T.ent_extra[v];
             if (ex != 0) xs[(L::WX + ex - 1) * 64] = wv;   // this node is an extra of earlier pivots
           }
         }
@@ -452,7 +676,18 @@ __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, doub
           const int base = p.offL + L0 + nx * NS;
           static_for<0, NS>([&](auto sc) { constexpr int s = decltype(sc)::value; lb[rs][s] = io.template ldk<s>(base); });   // l_1..l_B, 1/L_jj
           lb[rs][NS] = io.ld(p.offY + e0 + nx);
+          if constexpr (PFX) {
+            am_r[rs] = am_q; ex_r[rs] = ex_q;
+            if (am_q != 0) {
+              int k = k_q;
+              static_for<0, NXM>([&](auto sc) {
+                constexpr int sl = decltype(sc)::value;
+                if (am_q & (1 << sl)) { lxv[rs][sl] = io.ld(k); ++k; }
+              });
+            }
+          }
         }
+        if constexpr (PFX) tables(nx - 1);
       }
     });
   }
@@ -608,6 +843,120 @@ __global__ __launch_bounds__(64) void fom_band_lds_kernel(BandDev p, const int* 
     for (int i = 0; i < 4 && i < p.n_obs; ++i) qoi[i] = (double)(tk[i + 1] - tk[i]);
 }
 
+// WV waves per 64 samples: the eight fins are independent (shared over the waves), the post's forward sweep is band_sweep_ldsw,
+// its backward sweep runs on wave 0 with a deeper column ring
+template <int NSF, int NSP, int NXM, int WV>
+__global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(BandDev p, const int* __restrict__ abmap, const double* __restrict__ Fg,
+                                                              const int* __restrict__ act,
+                                                              const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra,
+                                                              const int* __restrict__ ecp_ptr, const int* __restrict__ ecp_slot,
+                                                              const int* __restrict__ ecp_off, const int* __restrict__ schur_off,
+                                                              const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr,
+                                                              const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                              double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,
+                                                              int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double xlds[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t blk = blockIdx.x;
+  double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;
+  Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000), lane * 8};
+  double* xs = xlds + lane;
+  const PostTables T{act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off};
+  constexpr int FLAG = (NSP - 1) * NSP / 2 + 2 * (NSP + 1) + NSP;      // behind band_sweep_ldsw's window
+  int bad = 0;
+  constexpr int NIFT = (NSF - 1) * NSF / 2;
+  long long tk[6];
+  tk[0] = wall_clock64();
+  {
+    double win[NSF * (NSF + 1) / 2], yw[NSF];
+    for (int f = wv; f < p.nfins; f += WV) {
+      const int npiv = p.npf, ntot = p.npf + p.nif;
+      band_sweep<NSF, false, NXM>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      int k = 0;
+      for (int t = 0; t < p.nif; ++t)
+        for (int s = 0; s <= t; ++s, ++k) {
+          const int a = (npiv + t) % NSF, b = (npiv + s) % NSF;
+          double v = 0.0;
+          static_for<0, NSF>([&](auto ac) {
+            static_for<0, decltype(ac)::value + 1>([&](auto bc) {
+              constexpr int ua = decltype(ac)::value, ub = decltype(bc)::value;
+              v = ((a == ua && b == ub) || (a == ub && b == ua)) ? win[tri(ua, ub)] : v;
+            });
+          });
+          const int off = schur_off[f * NIFT + k];
+          io.st(io.ld(off) + v, off);
+        }
+    }
+  }
+  __syncthreads();                                       // the fins' Schur complements are in the post's value slots (same CU: same L1)
+  tk[1] = wall_clock64();
+  {
+    int badp = 0;
+#define FR_W(I) case I: if constexpr (I < WV) band_sweep_ldsw<NSP, NXM, WV, I>(p, io, xs, Fg, abmap, T, p.post_g0, p.post_e0, p.npost, p.npost, p.post_L0, badp); break;
+    switch (wv) { FR_W(0) FR_W(1) FR_W(2) FR_W(3) default: break; }
+#undef FR_W
+    bad |= badp;
+  }
+  tk[2] = wall_clock64();
+  if (wv == 0) band_bsweep<NSP, true, NXM, 4>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
+  __syncthreads();
+  tk[3] = wall_clock64();
+  for (int f = wv; f < p.nfins; f += WV)
+    band_bsweep<NSF, false, NXM>(p, io, xs, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF);
+  xs[FLAG * 64] = 0.0;
+  __syncthreads();
+  if (bad) xs[FLAG * 64] = 1.0;                          // a fin's wave may be the only one that saw its failure
+  __syncthreads();
+  bad = xs[FLAG * 64] != 0.0;
+  tk[4] = wall_clock64();
+
+  const int64_t s = blk * 64 + lane;
+  const double nanv = __builtin_nan("");
+  if (bad) {
+    for (int i = wv; i < p.n; i += WV) io.st(nanv, p.offY + i);
+    if (wv == 0 && info != nullptr && s < S) atomicOr(&info[s], 1);
+  }
+  for (int o = wv; o < p.n_obs; o += WV) {
+    double q0 = 0.0, q1 = 0.0;
+    const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
+    for (int t = t0; t < t1; t += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = io.ld(p.offY + obs_idx[(t + u < t1) ? t + u : t1 - 1]);
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        q0 = fma((t + u < t1) ? obs_w[t + u] : 0.0, v[u], q0);
+        q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
+      }
+    }
+    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q0 + q1;
+  }
+  if ((p.on & 2) && s == 0 && wv == 0) {                 // FINROM_BAND_TIMING: 100 MHz ticks per phase (after everybody's QoI)
+    __builtin_amdgcn_s_sleep(127);
+    for (int i = 0; i < 4 && i < p.n_obs; ++i) qoi[i] = (double)(tk[i + 1] - tk[i]);
+  }
+}
+
+template <int NSF, int NSP>
+int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
+  constexpr int NXM = 8, WV = 4;
+  static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
+  constexpr size_t lds_w = (size_t)((NSP - 1) * NSP / 2 + 2 * (NSP + 1) + NSP + 1) * 64 * sizeof(double);      // window | 2 x row B | y | flag
+  constexpr size_t lds_b = (size_t)(XL<NSP, NXM>::WX + NXM) * 64 * sizeof(double);
+  constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
+  static_assert(lds <= 160 * 1024, "LDS window");
+  static bool once = false;
+  if (!once) {
+    FR_HIP(hipFuncSetAttribute((const void*)fom_band_ldsw_kernel<NSF, NSP, NXM, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    once = true;
+  }
+  hipLaunchKernelGGL((fom_band_ldsw_kernel<NSF, NSP, NXM, WV>), dim3((unsigned)nblk), dim3(64 * WV), lds, st, p, p.abmap, p.Fg, p.act,
+                     p.lx_ptr, p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx,
+                     p.obs_w, Gw, S, qoi, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int NSF, int NSP>
 int launch_lds(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int NXM = 8;
@@ -652,8 +1001,9 @@ int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, doubl
   if (p.NSF == 3 && p.NSP == 6) return launch_t<3, 6>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 4 && p.NSP == 10) return launch_t<4, 10>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 5 && p.NSP == 14) return launch_t<5, 14>(p, Gw, nblk, S, qoi, info, st);
-  if (p.NSF == 6 && p.NSP == 18) return launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st);
-  if (p.NSF == 7 && p.NSP == 22) return launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st);
+  static const bool one_wave = getenv("FINROM_BAND_LDS_ONE_WAVE") != nullptr;      // (A/B: the single-wave LDS sweep)
+  if (p.NSF == 6 && p.NSP == 18) return one_wave ? launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<6, 18>(p, Gw, nblk, S, qoi, info, st);
+  if (p.NSF == 7 && p.NSP == 22) return one_wave ? launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<7, 22>(p, Gw, nblk, S, qoi, info, st);
   set_error("fom band sweep: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }
