@@ -35,6 +35,11 @@ constexpr __device__ __host__ int ent_s(int e) { int s = 1; while (e >= s) { e -
 constexpr __device__ __host__ int tri(int a, int b) { return a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a; }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// the columns of L are written once and read once: non-temporal (aux bit 1 = nt on gfx94x/95x) keeps them from displacing the
+// projection kernel's tables in L2 when the two kernels run side by side
+#ifndef BAND_STREAM_AUX
+#define BAND_STREAM_AUX 2
+#endif
 
 struct Io {                       // the wave's slice of the workspace as a buffer resource: SGPR offsets, no address arithmetic
   __amdgpu_buffer_rsrc_t r; int lane8;
@@ -42,13 +47,13 @@ struct Io {                       // the wave's slice of the workspace as a buff
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane8, elem * 512, 0));
   }
   template <int K> __device__ __forceinline__ double ldk(int elem) const {      // element elem + K, K folded into the offset field
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane8 + (K % 8) * 512, (elem + K / 8 * 8) * 512, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, lane8 + (K % 8) * 512, (elem + K / 8 * 8) * 512, BAND_STREAM_AUX));
   }
   __device__ __forceinline__ void st(double v, int elem) const {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, lane8, elem * 512, 0);
   }
   template <int K> __device__ __forceinline__ void stk(double v, int elem) const {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, lane8 + (K % 8) * 512, (elem + K / 8 * 8) * 512, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, lane8 + (K % 8) * 512, (elem + K / 8 * 8) * 512, BAND_STREAM_AUX);
   }
 };
 

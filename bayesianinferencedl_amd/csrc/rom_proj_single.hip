@@ -18,8 +18,10 @@ __global__ __launch_bounds__(256, 2) void rom_proj_single_kernel(RomDev p, const
 int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                            hipStream_t st, double* w_r, double* qoi_r, int* /*cu_ticket: unused (stagger experiment)*/) {
   const dim3 grid((unsigned)((S + 3) / 4)), block(256);
+  static const size_t pad_lds = getenv("FINROM_PROJ_PAD_LDS") != nullptr ? (size_t)atoi(getenv("FINROM_PROJ_PAD_LDS")) : 0;      // occupancy experiments
   switch (p.NB) {
-#define FR_ONE(N) case N: hipLaunchKernelGGL(rom_proj_single_kernel<N>, grid, block, 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta); break;
+#define FR_ONE(N) case N: if (pad_lds > 65536) (void)hipFuncSetAttribute((const void*)rom_proj_single_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds); \
+                       hipLaunchKernelGGL(rom_proj_single_kernel<N>, grid, block, pad_lds, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta); break;
     FR_ONE(1) FR_ONE(2) FR_ONE(3) FR_ONE(4) FR_ONE(5)
 #undef FR_ONE
     default: set_error("rom_proj_single: basis size > 80"); return FINROM_ERR_UNSUPPORTED;
