@@ -851,7 +851,7 @@ __global__ __launch_bounds__(64) void fom_band_lds_kernel(BandDev p, const int* 
 // WV waves per 64 samples: the eight fins are independent (shared over the waves), the post's forward sweep is band_sweep_ldsw,
 // its backward sweep runs on wave 0 with a deeper column ring
 template <int NSF, int NSP, int NXM, int WV>
-__global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(BandDev p, const int* __restrict__ abmap, const double* __restrict__ Fg,
+__device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* __restrict__ abmap, const double* __restrict__ Fg,
                                                               const int* __restrict__ act,
                                                               const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra,
                                                               const int* __restrict__ ecp_ptr, const int* __restrict__ ecp_slot,
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(BandDev p, const
     bad |= badp;
   }
   tk[2] = wall_clock64();
-  if (wv == 0) band_bsweep<NSP, true, NXM, 4>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
+  if (wv == 0) band_bsweep<NSP, true, NXM, (NSP <= 14 ? 2 : 4)>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
   __syncthreads();
   tk[3] = wall_clock64();
   for (int f = wv; f < p.nfins; f += WV)
@@ -942,9 +942,18 @@ __global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(BandDev p, const
   }
 }
 
-template <int NSF, int NSP>
+#define FR_BAND_ARGS BandDev p, const int* __restrict__ abmap, const double* __restrict__ Fg, const int* __restrict__ act,                  \
+    const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra, const int* __restrict__ ecp_ptr, const int* __restrict__ ecp_slot,  \
+    const int* __restrict__ ecp_off, const int* __restrict__ schur_off, const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr, \
+    const int* __restrict__ obs_idx, const double* __restrict__ obs_w, double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,       \
+    int* __restrict__ info
+#define FR_BAND_PASS p, abmap, Fg, act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off, schur_off, iface_elim, obs_ptr, obs_idx, obs_w, Gw, S, qoi, info
+template <int NSF, int NSP, int NXM, int WV>
+__global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(FR_BAND_ARGS) { fom_band_ldsw_body<NSF, NSP, NXM, WV>(FR_BAND_PASS); }
+
+template <int NSF, int NSP, int NXM = 8>
 int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
-  constexpr int NXM = 8, WV = 4;
+  constexpr int WV = 4;
   static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
   constexpr size_t lds_w = (size_t)((NSP - 1) * NSP / 2 + 2 * (NSP + 1) + NSP + 1) * 64 * sizeof(double);      // window | 2 x row B | y | flag
   constexpr size_t lds_b = (size_t)(XL<NSP, NXM>::WX + NXM) * 64 * sizeof(double);
@@ -1006,9 +1015,13 @@ int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, doubl
   if (p.NSF == 3 && p.NSP == 6) return launch_t<3, 6>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 4 && p.NSP == 10) return launch_t<4, 10>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 5 && p.NSP == 14) return launch_t<5, 14>(p, Gw, nblk, S, qoi, info, st);
-  static const bool one_wave = getenv("FINROM_BAND_LDS_ONE_WAVE") != nullptr;      // (A/B: the single-wave LDS sweep)
-  if (p.NSF == 6 && p.NSP == 18) return one_wave ? launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<6, 18>(p, Gw, nblk, S, qoi, info, st);
-  if (p.NSF == 7 && p.NSP == 22) return one_wave ? launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<7, 22>(p, Gw, nblk, S, qoi, info, st);
+#ifdef FINROM_BUILD_ONE_WAVE_LDS      // A/B: the single-wave LDS sweep (a minute of compile time; -DFINROM_BUILD_ONE_WAVE_LDS + FINROM_BAND_LDS_ONE_WAVE=1)
+  static const bool one_wave = getenv("FINROM_BAND_LDS_ONE_WAVE") != nullptr;
+  if (one_wave && p.NSF == 6 && p.NSP == 18) return launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st);
+  if (one_wave && p.NSF == 7 && p.NSP == 22) return launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st);
+#endif
+  if (p.NSF == 6 && p.NSP == 18) return launch_ldsw<6, 18>(p, Gw, nblk, S, qoi, info, st);
+  if (p.NSF == 7 && p.NSP == 22) return launch_ldsw<7, 22>(p, Gw, nblk, S, qoi, info, st);
   set_error("fom band sweep: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }
