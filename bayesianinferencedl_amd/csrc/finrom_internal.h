@@ -214,6 +214,9 @@ int launch_rom_grad_contract(const RomDev& p, int64_t S, const RomGradArgs& ga, 
 int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, hipStream_t st);
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st,
                     double* w_r = nullptr, double* qoi_r = nullptr, int* cu_ticket = nullptr);
+constexpr int ROM_SPLITK_MAX_S = 64;      // batches up to this size take the split-K projection kernel (r = 49..96)
+int launch_rom_proj_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                           hipStream_t st, double* w_r, double* qoi_r);
 int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                            hipStream_t st, double* w_r, double* qoi_r, int* cu_ticket);   // cu_ticket: 4096 ints of device scratch or nullptr
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r,

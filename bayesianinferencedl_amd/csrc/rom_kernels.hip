@@ -311,6 +311,10 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
       default: break;
     }
   }
+  // one-sample call patterns (MAP / HMC): a lone wave per sample is pure MFMA latency; split its k-steps over four waves
+  static const bool no_splitk = getenv("FINROM_NO_SPLITK") != nullptr;
+  if (S <= ROM_SPLITK_MAX_S && p.NB >= 4 && p.NB <= 6 && p.nku >= 64 && !no_splitk)
+    return launch_rom_proj_splitk(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
   dim3 block(256);
 #define FR_CASE(N, W)                                                                              \
   case N: { constexpr int wpb = W > 4 ? W : 4; constexpr int spb = wpb / W;                        \

@@ -19,6 +19,8 @@ __device__ __forceinline__ void sfor(F&& f) {
 //   tv[((slot0 + (ks - ks0) * nt + t) * 4 + q) * rp + col],   theta index pidx[(slot) * 4 + q],
 // i.e. every address is a function of the loop counter (no dependent index loads), and the raw
 // table values of k-step ks+1 are fetched into registers while the MFMAs of k-step ks issue.
+// (These phase tables serve psi^T F on the root rows and the FINROM_CLOCK_PROBE=3 A/B loop; the main loops run on the
+// pattern-uniform tables RomDev::tvu / kmeta, see proj_main_uniform / proj_main_uniform_mw below.)
 constexpr int ROM_MAX_NT = 4;
 
 template <int NB>
@@ -35,25 +37,6 @@ __device__ __forceinline__ void load_kstep(const double* __restrict__ tv, const 
       const double* src = tv + (int64_t)row * rp + c;
 #pragma unroll
       for (int b = 0; b < NB; ++b) raw[t][b] = src[16 * b];
-    }
-  }
-}
-
-// NW > 1 waves share a sample: wave W builds only the blocks W, W + NW, ... of the slab (own index j <-> block W + j NW)
-template <int NB, int NW, int W>
-__device__ __forceinline__ void load_kstep_own(const double* __restrict__ tv, const int* __restrict__ pidx, int slot, int nt,
-                                               int rp, int q, int c, double (&raw)[ROM_MAX_NT][(NB - W + NW - 1) / NW],
-                                               int (&pi)[ROM_MAX_NT]) {
-  constexpr int NOWN = (NB - W + NW - 1) / NW;
-#pragma unroll
-  for (int t = 0; t < ROM_MAX_NT; ++t) pi[t] = pidx[(slot + t) * 4 + q];
-#pragma unroll
-  for (int t = 0; t < ROM_MAX_NT; ++t) {
-    if (t < nt) {                                  // wave-uniform
-      const int row = (slot + t) * 4 + q;
-      const double* src = tv + (int64_t)row * rp + c;
-#pragma unroll
-      for (int j = 0; j < NOWN; ++j) raw[t][j] = src[16 * (W + j * NW)];
     }
   }
 }
@@ -267,7 +250,7 @@ template <int NB> constexpr int tile_tj(int i) { int ti = 0; while (i >= NB - ti
 template <int NB>
 __device__ __forceinline__ void proj_main_uniform(const RomDev& p, const int* __restrict__ kmeta_g,
                                                   const double* __restrict__ theta_g, int q, int c,
-                                                  d4 (&acc)[NB * (NB + 1) / 2]) {
+                                                  d4 (&acc)[NB * (NB + 1) / 2], int nku) {
   constexpr int NTL = NB * (NB + 1) / 2;
   typedef const i4 __attribute__((address_space(4)))* c_i4_p;
   const c_i4_p kmeta = (c_i4_p)(unsigned long long)kmeta_g;             // record ks = kmeta[2 ks] (slot, nt, -, -), kmeta[2 ks + 1] (theta indices)
@@ -333,7 +316,6 @@ __device__ __forceinline__ void proj_main_uniform(const RomDev& p, const int* __
     sfor<0, ROM_MAX_NT>([&](auto tc) { th1[decltype(tc)::value] = th2[decltype(tc)::value]; });
     nt1 = m2[1]; m2 = m3; k2 = k3;
   };
-  const int nku = p.nku;
 #pragma unroll 1
   for (int ks = 0; ks < nku; ks += 2) {
     step(va, vb, ks);
@@ -640,7 +622,10 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                               int* __restrict__ info, double* __restrict__ w_r = nullptr,
                                               double* __restrict__ qoi_r = nullptr, double* slab = nullptr,
-                                              const double* __restrict__ theta_s = nullptr, const int* __restrict__ kpat = nullptr) {
+                                              const double* __restrict__ theta_s = nullptr, const int* __restrict__ kpat = nullptr,
+                                              int kpart = 0, int kparts = 1) {
+  // kparts > 1 (NW == 1, small batches): the sample's k-steps are split over the kparts waves of the workgroup, the partial
+  // block triangles are summed through LDS (`slab`) in a fixed order and wave 0 alone runs the epilogue
   constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
   const int q = lane >> 4, c = lane & 15;
   d4 acc[NTL];
@@ -655,7 +640,11 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     // copy of the kernel arguments in scratch memory once the fused epilogue was added)
     proj_main_uniform_mw<NB, NW, W>(p, kpat, theta_s, q, c, lane, slab, acc);
   } else if ((p.clock_probe & 15) != 3) {      // (bits 4 / 5: timing experiments without table loads / without scalar loads)
-    proj_main_uniform<NB>(p, kpat, theta_s, q, c, acc);      // kpat = RomDev::kmeta as a kernel parameter  // (FINROM_CLOCK_PROBE=3: the per-lane-theta loop below, for A/B timing)
+    if constexpr (NW == 1) {
+      const int per = ((p.nku + kparts - 1) / kparts + 1) / 2 * 2, k0 = kpart * per;
+      const int cnt = kparts == 1 ? p.nku : (k0 >= p.nku ? 0 : (p.nku - k0 < per ? p.nku - k0 : per));
+      if (cnt > 0) proj_main_uniform<NB>(p, kpat + 8 * k0, theta_s, q, c, acc, cnt);      // kpat = RomDev::kmeta as a kernel parameter  // (FINROM_CLOCK_PROBE=3: the per-lane-theta loop below, for A/B timing)
+    }
   } else
   // ONE copy of the MFMA group for all phases (runtime term count): several unrolled copies make hipcc
   // spill the inline-asm accumulators around every copy
@@ -699,6 +688,23 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 
   // let the last MFMAs retire before their results are read (no hazard padding around inline asm)
   mfma_drain(acc);
+  if constexpr (NW == 1) {
+    if (kparts > 1) {
+      if (kpart > 0) {
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) slab[((kpart - 1) * NTL + t) * 256 + g * 64 + lane] = acc[t][g];
+      }
+      __syncthreads();
+      if (kpart > 0) return;
+      for (int w = 1; w < kparts; ++w)
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[t][g] += slab[((w - 1) * NTL + t) * 256 + g * 64 + lane];
+    }
+  }
   int bad = 0;
   if constexpr (NW == 1 && NB <= 6) {
     if (factor) {      // A_r = U^T U in registers; what is written below is then U^T (= L, packed by columns)
@@ -790,6 +796,28 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
   if constexpr (NW > 1) {
     if (factor == 3) fused_solve_mw<NB, NW, W>(p, acc, bacc, s, lane, slab, qoi_r, info);
   }
+}
+
+// Small batches (one-sample call patterns: MAP / HMC): ONE sample per workgroup, its k-steps split over the KS waves -- a lone
+// wave walking all 400 k-steps is 0.23 ms of pure MFMA latency at r = 81; four waves take a quarter each and hand their partial
+// block triangles to wave 0 through LDS ((KS - 1) x NT tiles of 2 KB: dynamic shared memory)
+template <int NB, int KS>
+__device__ __forceinline__ void rom_proj_entry_splitk(RomDev p, const double* __restrict__ theta, int64_t S,
+                                                      double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                                      int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
+                                                      const int* __restrict__ kpat) {
+  extern __shared__ __attribute__((aligned(16))) double red_lds[];
+  __shared__ double th[KS][32];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t s = blockIdx.x;
+  if (s >= S) return;
+  if (lane == 0) { th[wave][0] = 1.0; th[wave][p.P + 1] = 0.0; }
+  if (lane < p.P) th[wave][lane + 1] = theta[s * p.P + lane];
+  __builtin_amdgcn_wave_barrier();
+  const unsigned long long ta = (unsigned long long)(theta + (int64_t)blockIdx.x * p.P);
+  const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));
+  rom_proj_body<NB, 1, 0>(p, th[wave], s, lane, Ar, Br, factor, info, w_r, qoi_r, red_lds, theta_s, kpat, wave, KS);
 }
 
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a

@@ -15,6 +15,36 @@ __global__ __launch_bounds__(256, 2) void rom_proj_single_kernel(RomDev p, const
   rom_proj_entry<NB, 1>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
 }
 
+// small batches: the sample's k-steps split over four waves (rom_proj_entry_splitk)
+template <int NB>
+__global__ __launch_bounds__(256, 1) void rom_proj_splitk_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+                                                                 double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                                                 int* __restrict__ info, double* __restrict__ w_r,
+                                                                 double* __restrict__ qoi_r, const int* __restrict__ kpat) {
+  rom_proj_entry_splitk<NB, 4>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
+}
+
+template <int NB>
+static int launch_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                         hipStream_t st, double* w_r, double* qoi_r) {
+  constexpr int lds = 3 * (NB * (NB + 1) / 2) * 256 * (int)sizeof(double);
+  static bool once = false;
+  if (!once) { FR_HIP(hipFuncSetAttribute((const void*)rom_proj_splitk_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  hipLaunchKernelGGL(rom_proj_splitk_kernel<NB>, dim3((unsigned)S), dim3(256), lds, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_rom_proj_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                           hipStream_t st, double* w_r, double* qoi_r) {
+  switch (p.NB) {
+    case 4: return launch_splitk<4>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+    case 5: return launch_splitk<5>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+    case 6: return launch_splitk<6>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+    default: set_error("rom_proj_splitk: basis size"); return FINROM_ERR_UNSUPPORTED;
+  }
+}
+
 int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                            hipStream_t st, double* w_r, double* qoi_r, int* /*cu_ticket: unused (stagger experiment)*/) {
   const dim3 grid((unsigned)((S + 3) / 4)), block(256);

@@ -438,6 +438,7 @@ def run_hmc(args, rank, local_rank, world):
         ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in prof.items()}
         dom = max(prof, key=lambda k: prof[k][1]) if any(v[1] for v in prof.values()) else None
         roof = None
+        pairs_n_obs = len(solver_r.data)
         if dom == "rom_proj_mfma" and ms[dom] > 0 and args.projection == "direct":
             ops = V.operators()
             alg = len(mine) * (ops.n * r * (r + 1) + 2 * solver_r._rom.nterms * r + r ** 3 // 3)
@@ -445,6 +446,15 @@ def run_hmc(args, rank, local_rank, world):
             roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms[dom],
                     "note": "latency-bound workload: one wave per chain runs the whole contraction; the fraction is what one call leaves of the chip, not a kernel-quality figure"}
+        elif dom == "rom_reduced_solve" and ms[dom] > 0:
+            # substitutions + adjoint + gradient contraction on the stored factor: what has to move per call is the packed factor
+            # (read by both solves) and the vectors; one wave per chain, so this, too, is a latency figure
+            rp = (r + 15) // 16 * 16
+            alg = len(mine) * 8 * (2 * (rp * (rp + 1) // 2) + 4 * rp + pairs_n_obs + 9)
+            ach = alg / (ms[dom] * 1e-3) / 1e9
+            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                    "traffic": None, "avg_launch_ms": ms[dom],
+                    "note": "latency-bound workload: one wave per chain walks 2 r pivot steps; lower-bound bytes (factor read twice + vectors)"}
         cpu = None
         if world == 1 and args.cpu_samples > 0:
             cpu = hmc_cpu_baseline(args, phi, model, solver_r.data, K0, res)

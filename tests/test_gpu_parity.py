@@ -75,7 +75,7 @@ def test_rom_parity(problems, spaces, m, r):
     phi = oracle_basis(prob, r)
     ro = O.AffineROMOracle(prob, phi)
     rng = np.random.default_rng(4)
-    TH = rng.uniform(0.1, 3.5, (50, 9))
+    TH = rng.uniform(0.1, 3.5, (130, 9))               # > 64 samples: the throughput kernels (small batches: see the end)
     rom = AffineROMFin(V, None, phi)
     res = rom.forward_nine_param_reduced_batch(TH, want_state=True)
     assert (res["info"] == 0).all()
@@ -103,6 +103,14 @@ def test_rom_parity(problems, spaces, m, r):
     assert "w_r" not in qonly and (qonly["info"] == 0).all()
     assert rel(qonly["qoi_r"][:n_check], WR @ ro.B_obs_phi.T) < TOL
     assert rel(qonly["qoi_r"], res["qoi_r"]) < TOL
+    # batches of <= 64 samples (one-sample call patterns) split a sample's k-steps over four waves for 48 < r <= 96
+    # (rom_proj_entry_splitk): another summation order, same contract, with and without the A_r / B_r outputs
+    small = rom.forward_nine_param_reduced_batch(TH[:7], want_state=True)
+    assert (small["info"] == 0).all()
+    assert rel(small["A_r"].reshape(7, -1), AR[:7].reshape(7, -1)) < 1e-12 and rel(small["B_r"], BR[:7]) < 1e-12
+    assert rel(small["qoi_r"], WR[:7] @ ro.B_obs_phi.T) < TOL and rel(small["w_r"] @ phi.T, WR[:7] @ phi.T) < TOL
+    small = rom.forward_nine_param_reduced_batch(TH[:7])
+    assert rel(small["qoi_r"], WR[:7] @ ro.B_obs_phi.T) < TOL and rel(small["w_r"] @ phi.T, WR[:7] @ phi.T) < TOL
 
 
 def test_pairs_field_parity(problems, spaces):
