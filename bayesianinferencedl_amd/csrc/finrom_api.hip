@@ -87,7 +87,7 @@ struct finrom_fom_s {
 struct finrom_rom_s {
   RomDev d{};
   std::vector<void*> owned;
-  Scratch Ar, Br, theta, qtmp, vw, ticket;
+  Scratch Ar, Br, theta, qtmp, vw, ticket, grad_ticket;
   int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
   RomGramDev gram;                     // offline/online form (finrom_rom_set_gram); gram.h is filled at create
   int projection = FINROM_PROJECTION_DIRECT;
@@ -859,7 +859,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
 void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release(); h->ticket.release();
+  h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release(); h->ticket.release(); h->grad_ticket.release();
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -998,6 +998,28 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
     if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
     double* q = qoi_r ? qoi_r + s0 * d.n_obs : nullptr;
     if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
+    // one-sample call patterns (MAP / HMC), 48 < r <= 96, the per-sample contraction: projection split over four waves, both
+    // solves in registers, the gradient contraction dealt over the same waves -- one kernel, nothing but the outputs written
+    if (h->projection == FINROM_PROJECTION_DIRECT && rom_splitk_applies(d, Sc) && d.n_obs <= 64 && getenv("FINROM_OLD_SUBST") == nullptr) {
+      RomGradArgs ga;
+      ga.data = data + (data_per_sample ? s0 * d.n_obs : 0); ga.data_stride = data_per_sample ? d.n_obs : 0;
+      ga.theta = theta + s0 * d.P; ga.J = J + s0; ga.g = g + s0 * d.P;
+      ga.npairs = h->g_npairs; ga.pair_p = h->g_pair_p; ga.pair_i = h->g_pair_i; ga.Gt = h->g_Gt;
+      const size_t vw_bytes = (size_t)Sc * 2 * d.rp * sizeof(double), gp_bytes = (size_t)Sc * ROM_GRAD_SMALL_NG * 32 * sizeof(double);
+      if ((rc = h->vw.reserve(vw_bytes + gp_bytes))) return rc;
+      if (!h->grad_ticket.p) {                          // arrival counters: zero once, the kernel leaves them zero
+        if ((rc = h->grad_ticket.reserve(ROM_SPLITK_MAX_S * sizeof(int)))) return rc;
+        FR_HIP(hipMemsetAsync(h->grad_ticket.p, 0, ROM_SPLITK_MAX_S * sizeof(int), st));
+      }
+      ga.vw = (double*)h->vw.p; ga.gpart = (double*)((char*)h->vw.p + vw_bytes); ga.ticket = (int*)h->grad_ticket.p;
+      {
+        ScopedKernelTimer t(K_ROM_PROJ, st);
+        if ((rc = launch_rom_proj_splitk(d, theta + s0 * d.P, Sc, (double*)h->Ar.p, (double*)h->Br.p, 4, info ? info + s0 : nullptr, st,
+                                         w_r ? w_r + s0 * d.r : nullptr, q, ga))) return rc;
+      }
+      if ((rc = launch_rom_grad_contract_small(d, Sc, ga, st))) return rc;
+      continue;
+    }
     // the factor of A_r: inside the projection kernel for r <= 96, by the blocked MFMA Cholesky kernel for wider bases
     if ((rc = rom_project(h, theta + s0 * d.P, Sc, d.NB <= 6 ? 1 : 0, info ? info + s0 : nullptr, st))) return rc;
     if (d.NB > 6 && (rc = launch_rom_chol_blocked(d, (double*)h->Ar.p, Sc, info ? info + s0 : nullptr, st))) return rc;

@@ -194,6 +194,7 @@ struct RomGradArgs {                      // adjoint-gradient stage of rom_solve
   const double* theta = nullptr;                            // [S x P]
   double* J = nullptr; double* g = nullptr;                 // [S], [S x P]
   int npairs = 0; const int* pair_p = nullptr; const int* pair_i = nullptr; const double* Gt = nullptr;
+  double* gpart = nullptr; int* ticket = nullptr;   // small batches (rom_grad_contract_small_kernel): [S x NG x 32] partial sums, [S] arrival counters (zero between calls)
   double* vw = nullptr;     // scratch [S x 2 rp]: when set, the substitution kernel leaves v_r and w_r there and the
                             // contraction g_i = sum_p theta_p v_r^T G_pi w_r runs in rom_grad_contract_kernel (fp64 MFMA, 16 samples per wave)
 };
@@ -215,8 +216,11 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st,
                     double* w_r = nullptr, double* qoi_r = nullptr, int* cu_ticket = nullptr);
 constexpr int ROM_SPLITK_MAX_S = 64;      // batches up to this size take the split-K projection kernel (r = 49..96)
+bool rom_splitk_applies(const RomDev& p, int64_t S);
+constexpr int ROM_GRAD_SMALL_NG = 36;      // blocks per sample in rom_grad_contract_small_kernel
+int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st);
 int launch_rom_proj_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
-                           hipStream_t st, double* w_r, double* qoi_r);
+                           hipStream_t st, double* w_r, double* qoi_r, const RomGradArgs& ga);
 int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                            hipStream_t st, double* w_r, double* qoi_r, int* cu_ticket);   // cu_ticket: 4096 ints of device scratch or nullptr
 int launch_rom_solve(const RomDev& p, const double* Ar, const double* Br, int64_t S, double* w_r,

@@ -312,9 +312,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
     }
   }
   // one-sample call patterns (MAP / HMC): a lone wave per sample is pure MFMA latency; split its k-steps over four waves
-  static const bool no_splitk = getenv("FINROM_NO_SPLITK") != nullptr;
-  if (S <= ROM_SPLITK_MAX_S && p.NB >= 4 && p.NB <= 6 && p.nku >= 64 && !no_splitk)
-    return launch_rom_proj_splitk(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+  if (rom_splitk_applies(p, S)) return launch_rom_proj_splitk(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, RomGradArgs());
   dim3 block(256);
 #define FR_CASE(N, W)                                                                              \
   case N: { constexpr int wpb = W > 4 ? W : 4; constexpr int spb = wpb / W;                        \
@@ -767,6 +765,63 @@ __global__ __launch_bounds__(64) void rom_grad_contract_kernel(RomDev p, int64_t
     const int sl = t / p.P, i = t - sl * p.P;
     if (s0 + sl < S) ga.g[(s0 + sl) * p.P + i] = gs[sl * 32 + i];
   }
+}
+
+// The same contraction for a handful of samples (one-sample call patterns): latency, not throughput -- ROM_GRAD_SMALL_NG
+// workgroups per sample, each walks its share of the blocks G_pi as flat arrays (64 consecutive entries per step, 16 steps in
+// flight) with v_r, w_r in LDS; the last workgroup to arrive (ticket) adds the partial sums in a fixed order.
+__global__ __launch_bounds__(64) void rom_grad_contract_small_kernel(RomDev p, int64_t S, RomGradArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) double cs[];
+  const int r = p.r, R = p.rp, lane = threadIdx.x, grp = blockIdx.y, NG = gridDim.y;
+  const int64_t s = blockIdx.x;
+  double* vs = cs; double* ws = cs + R;
+  for (int t = lane; t < 2 * R; t += 64) cs[t] = ga.vw[s * (int64_t)(2 * R) + t];
+  __syncthreads();
+  double g = 0.0;
+  for (int pi = grp; pi < ga.npairs; pi += NG) {
+    const double* __restrict__ G = ga.Gt + (int64_t)pi * r * r;      // G[c r + row]
+    const int n = r * r;
+    double part = 0.0;
+    int c2 = 0, row = lane;                              // entry base + lane = c2 r + row
+    while (row >= r) { row -= r; ++c2; }
+    for (int base = 0; base < n; base += 64 * 16) {
+      double gv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const int idx = base + u * 64 + lane; gv[u] = idx < n ? G[idx] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        if (base + u * 64 + lane < n) part = fma(gv[u] * vs[row], ws[c2], part);
+        row += 64;
+        if (row >= r) { row -= r; ++c2; }
+        if (row >= r) { row -= r; ++c2; }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    const int pp = ga.pair_p[pi];
+    const double thp = pp == 0 ? 1.0 : ga.theta[s * p.P + pp - 1];
+    if (lane == ga.pair_i[pi]) g = fma(thp, part, g);
+  }
+  if (lane < 32) ga.gpart[(s * NG + grp) * 32 + lane] = g;
+  __threadfence();
+  int last = 0;
+  if (lane == 0) last = atomicAdd(&ga.ticket[s], 1) == NG - 1;
+  last = __shfl(last, 0);
+  if (!last) return;
+  __threadfence();                                       // the other workgroups' partial sums are visible
+  if (lane < p.P) {
+    double t = 0.0;
+    for (int w = 0; w < NG; ++w) t += ga.gpart[(s * NG + w) * 32 + lane];
+    ga.g[s * p.P + lane] = t;
+  }
+  if (lane == 0) ga.ticket[s] = 0;                       // ready for the next call
+}
+
+int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st) {
+  if (S == 0) return 0;
+  ScopedKernelTimer t(K_ROM_SOLVE, st);
+  hipLaunchKernelGGL(rom_grad_contract_small_kernel, dim3((unsigned)S, ROM_GRAD_SMALL_NG), dim3(64), (size_t)2 * p.rp * sizeof(double), st, p, S, ga);
+  FR_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_rom_grad_contract(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st) {

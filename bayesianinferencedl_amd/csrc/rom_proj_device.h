@@ -617,13 +617,13 @@ __device__ __forceinline__ void fused_solve_mw(const RomDev& p, d4 (&acc)[(NB * 
   }
 }
 
-template <int NB, int NW, int W>
+template <int NB, int NW, int W, bool SK = false>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                               int* __restrict__ info, double* __restrict__ w_r = nullptr,
                                               double* __restrict__ qoi_r = nullptr, double* slab = nullptr,
                                               const double* __restrict__ theta_s = nullptr, const int* __restrict__ kpat = nullptr,
-                                              int kpart = 0, int kparts = 1) {
+                                              int kpart = 0, int kparts = 1, const RomGradArgs* ga = nullptr) {
   // kparts > 1 (NW == 1, small batches): the sample's k-steps are split over the kparts waves of the workgroup, the partial
   // block triangles are summed through LDS (`slab`) in a fixed order and wave 0 alone runs the epilogue
   constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
@@ -714,7 +714,8 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
   }
   // factor == 2: substitutions + QoI below, nothing stored but w_r, qoi_r (r <= 80)
   // factor == 3 (multi-wave kernels): factorisation + QoI in registers, nothing stored but qoi_r (fused_solve_mw)
-  const bool fused_solve = (NW == 1 && NB <= 5 && factor == 2) || (NW > 1 && factor == 3);
+  // factor == 4 (split-K kernel, SK): also the adjoint solve; v_r, w_r go to RomGradArgs::vw for rom_grad_contract_small_kernel
+  const bool fused_solve = (NW == 1 && (NB <= 5 || SK) && (factor == 2 || (SK && factor == 4))) || (NW > 1 && factor == 3);
   // C/D layout of v_mfma_f64_16x16x4_f64: lane holds D[row = (lane>>4) + 4*g][col = lane&15].
   // A_r is symmetric: tile (ti <= tj) element (row, col) is written as the LOWER element
   // (i = col, k = row) of the packed column-major lower triangle the solve kernel reads.
@@ -769,11 +770,62 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
       bacc[b] = x;                               // B_r[16 b + c], the same in all four row groups
       if (!fused_solve && q == 0) Br[s * p.rp + 16 * b + c] = x;
     }
-    if constexpr (NW == 1 && NB <= 5) {
+    if constexpr (NW == 1 && (NB <= 5 || SK)) {
       if (fused_solve) {
         double xr[NB];
         solve_tiles<NB>(acc, bacc, q, c, xr);
         const double nanv = __builtin_nan("");
+        if constexpr (SK) {
+          if (factor == 4) {
+            // adjoint gradient (rom/averaged_affine_ROM.py:335-356), the solves in registers: residual of the observations,
+            // v_r = A_r^-1 (B_obs Phi)^T (data - qoi_r); w_r, v_r -> LDS for the contraction with the blocks G_pi
+            const int R = p.rp;
+            double* rs = slab;
+            const double* dat = ga->data + (ga->data_stride ? s * ga->data_stride : 0);
+            double jl = 0.0;
+            for (int o0 = 0; o0 < p.n_obs; o0 += 4) {
+              const int o = o0 + q;
+              double d = 0.0;
+#pragma unroll
+              for (int t = 0; t < NB; ++t)
+                if (o < p.n_obs && 16 * t + c < p.r) d = fma(p.obs_phi[o * p.r + 16 * t + c], xr[t], d);
+              d += __shfl_xor(d, 8); d += __shfl_xor(d, 4); d += __shfl_xor(d, 2); d += __shfl_xor(d, 1);
+              if (o < p.n_obs && c == 0) {
+                if (qoi_r != nullptr) qoi_r[s * p.n_obs + o] = bad ? nanv : d;
+                const double res = dat[o] - d;
+                rs[o] = res;
+                jl = fma(res, res, jl);
+              }
+            }
+            jl += __shfl_xor(jl, 16); jl += __shfl_xor(jl, 32);      // the four row groups' lanes c == 0
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            double b2[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) b2[t] = 0.0;
+            for (int o = q; o < p.n_obs; o += 4) {             // row group q takes observations q, q + 4, ...
+              const double ro = rs[o];
+#pragma unroll
+              for (int t = 0; t < NB; ++t)
+                if (16 * t + c < p.r) b2[t] = fma(p.obs_phi[o * p.r + 16 * t + c], ro, b2[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < NB; ++t) { double x = b2[t]; x += __shfl_xor(x, 16); x += __shfl_xor(x, 32); b2[t] = x; }
+            double vr[NB];
+            solve_tiles<NB>(acc, b2, q, c, vr);
+            if (q == 0) {                                    // v_r | w_r -> scratch for the contraction kernel (NaN marks a failed sample)
+              double* dst = ga->vw + s * (int64_t)(2 * R);
+#pragma unroll
+              for (int t = 0; t < NB; ++t) {
+                const bool in = 16 * t + c < p.r;
+                dst[16 * t + c] = in ? (bad ? nanv : vr[t]) : 0.0; dst[R + 16 * t + c] = in ? (bad ? nanv : xr[t]) : 0.0;
+                if (w_r != nullptr && in) w_r[s * p.r + 16 * t + c] = bad ? nanv : xr[t];
+              }
+            }
+            if (lane == 0) ga->J[s] = bad ? nanv : 0.5 * jl;
+            return;
+          }
+        }
         if (w_r != nullptr && q == 0) {
 #pragma unroll
           for (int t = 0; t < NB; ++t)
@@ -805,7 +857,7 @@ template <int NB, int KS>
 __device__ __forceinline__ void rom_proj_entry_splitk(RomDev p, const double* __restrict__ theta, int64_t S,
                                                       double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
-                                                      const int* __restrict__ kpat) {
+                                                      const int* __restrict__ kpat, const RomGradArgs& ga) {
   extern __shared__ __attribute__((aligned(16))) double red_lds[];
   __shared__ double th[KS][32];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -817,7 +869,7 @@ __device__ __forceinline__ void rom_proj_entry_splitk(RomDev p, const double* __
   const unsigned long long ta = (unsigned long long)(theta + (int64_t)blockIdx.x * p.P);
   const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));
-  rom_proj_body<NB, 1, 0>(p, th[wave], s, lane, Ar, Br, factor, info, w_r, qoi_r, red_lds, theta_s, kpat, wave, KS);
+  rom_proj_body<NB, 1, 0, true>(p, th[wave], s, lane, Ar, Br, factor, info, w_r, qoi_r, red_lds, theta_s, kpat, wave, KS, &ga);
 }
 
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a

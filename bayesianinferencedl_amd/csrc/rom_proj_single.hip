@@ -20,27 +20,34 @@ template <int NB>
 __global__ __launch_bounds__(256, 1) void rom_proj_splitk_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                                  double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                                  int* __restrict__ info, double* __restrict__ w_r,
-                                                                 double* __restrict__ qoi_r, const int* __restrict__ kpat) {
-  rom_proj_entry_splitk<NB, 4>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
+                                                                 double* __restrict__ qoi_r, const int* __restrict__ kpat, RomGradArgs ga) {
+  rom_proj_entry_splitk<NB, 4>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat, ga);
 }
 
 template <int NB>
 static int launch_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
-                         hipStream_t st, double* w_r, double* qoi_r) {
+                         hipStream_t st, double* w_r, double* qoi_r, const RomGradArgs& ga) {
   constexpr int lds = 3 * (NB * (NB + 1) / 2) * 256 * (int)sizeof(double);
   static bool once = false;
   if (!once) { FR_HIP(hipFuncSetAttribute((const void*)rom_proj_splitk_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
-  hipLaunchKernelGGL(rom_proj_splitk_kernel<NB>, dim3((unsigned)S), dim3(256), lds, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta);
+  hipLaunchKernelGGL(rom_proj_splitk_kernel<NB>, dim3((unsigned)S), dim3(256), lds, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta, ga);
   FR_HIP(hipGetLastError());
   return 0;
 }
 
+bool rom_splitk_applies(const RomDev& p, int64_t S) {
+  static const bool no_splitk = getenv("FINROM_NO_SPLITK") != nullptr;
+  return S <= ROM_SPLITK_MAX_S && p.NB >= 4 && p.NB <= 6 && p.nku >= 64 && !no_splitk;
+}
+
+// factor 0 / 1 / 2 as in launch_rom_proj; 4 (with ga): the whole adjoint gradient (finrom_rom_grad) in this one kernel
 int launch_rom_proj_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
-                           hipStream_t st, double* w_r, double* qoi_r) {
+                           hipStream_t st, double* w_r, double* qoi_r, const RomGradArgs& ga) {
+  if (S == 0) return 0;
   switch (p.NB) {
-    case 4: return launch_splitk<4>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
-    case 5: return launch_splitk<5>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
-    case 6: return launch_splitk<6>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+    case 4: return launch_splitk<4>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, ga);
+    case 5: return launch_splitk<5>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, ga);
+    case 6: return launch_splitk<6>(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, ga);
     default: set_error("rom_proj_splitk: basis size"); return FINROM_ERR_UNSUPPORTED;
   }
 }
