@@ -949,7 +949,7 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
     int factor = (want_factor && d.NB <= 6) ? 1 : 0;                  // in-register, inside the projection kernel
     // ... and when neither A_r nor B_r is wanted back (r <= 80), the two substitutions and the reduced QoI happen there
     // as well: no packed factor in memory, no second kernel
-    if (factor && d.NB <= 5 && A_r == nullptr && B_r == nullptr && getenv("FINROM_NO_FUSED_SOLVE") == nullptr &&
+    if (factor && (d.NB <= 5 || (d.NB == 6 && h->projection == FINROM_PROJECTION_DIRECT && rom_splitk_applies(d, Sc))) && A_r == nullptr && B_r == nullptr && getenv("FINROM_NO_FUSED_SOLVE") == nullptr &&
         getenv("FINROM_PROJ_LDS") == nullptr) factor = 2;
     // wider bases, only the reduced QoI wanted (the sample-pair path): factorisation and QoI stay in the registers of the
     // projection kernel's waves (fused_solve_mw); A_r never reaches memory
