@@ -133,6 +133,28 @@ class Fin:
         Jac = self.sensitivity(k)
         return Jac.T @ (Jac @ as_nodal(u_2))
 
+    def hessian_action(self, k, u_2, data):
+        """Full Hessian action of J = 1/2 |B_obs w(k) - data|^2 on a direction u_2 (reference :344-368), consistent with
+        `forward` / `gradient` (the operator is linear in k; the reference's incremental forms carry exp(k) although its forward
+        model does not -- its own TODO, :243-263 -- so its third, exp-only term has no counterpart here):
+            A w = F,   A lam = -B^T (B w - d),   A w^ = -A[u] w,   A lam^ = -B^T B w^ - A[u] lam,
+            (H u)_i = lam^^T A_i w + lam^T A_i w^,      A[u] = sum_i u_i A_i.
+        Four sparse solves with one factorisation on the HOST (SciPy SuperLU): an inverse-problem diagnostic outside the hot
+        path (not a row); `GN_hessian_action` and the gradients it is checked against run on the device."""
+        import scipy.sparse.linalg as spl
+        ops = self.ops
+        kk, u, d = as_nodal(k), as_nodal(u_2), np.asarray(data, dtype=np.float64)
+        W = ops.W_field
+        lu = spl.splu(ops.csr(ops.robin_vals + W @ kk).tocsc())
+        B = np.asarray(self.B_obs)
+        Au = ops.csr(W @ u)
+        w = lu.solve(np.asarray(ops.F, dtype=np.float64))
+        lam = lu.solve(-(B.T @ (B @ w - d)))
+        w_hat = lu.solve(-(Au @ w))
+        lam_hat = lu.solve(-(B.T @ (B @ w_hat)) - Au @ lam)
+        rows = np.repeat(np.arange(ops.n), np.diff(ops.indptr)); cols = ops.indices
+        return W.T @ (lam_hat[rows] * w[cols]) + W.T @ (lam[rows] * w_hat[cols])
+
     # ---- dense mass and stiffness matrices the reference keeps as attributes (:172-173; not used by the hot loop) ----------
     @property
     def M(self):

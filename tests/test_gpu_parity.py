@@ -594,3 +594,19 @@ def test_device_error_model_matches_the_host_network(problems, spaces):
             assert np.linalg.norm(res["grad"][s] - ref["grad"][s]) <= 1e-5 * np.linalg.norm(ref["grad"][s])
         go, lo = O.grad_romml_oracle(ro, model, K[2])
         assert abs(res["loss"][2] - lo) <= 2e-5 * abs(lo) and np.linalg.norm(res["grad"][2] - go) <= 1e-5 * np.linalg.norm(go)
+
+
+def test_hessian_action_matches_differences_of_the_device_gradient(spaces):
+    """Full Hessian action (host, four sparse solves) against central differences of the DEVICE adjoint gradient, and its
+    Gauss-Newton part against `GN_hessian_action` (device Jacobian) when the data are reproduced exactly (zero residual)."""
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    fin = Fin(spaces(8))
+    rng = np.random.default_rng(1)
+    k = np.exp(0.3 * rng.standard_normal(fin.dofs)); u = rng.standard_normal(fin.dofs)
+    d = rng.uniform(0.1, 1.0, fin.n_obs)
+    H = fin.hessian_action(k, u, d)
+    eps = 1e-4
+    fd = (fin.gradient(k + eps * u, d) - fin.gradient(k - eps * u, d)) / (2 * eps)
+    assert np.linalg.norm(H - fd) < 1e-6 * np.linalg.norm(fd)
+    q = fin.qoi_operator(fin.forward(k)[0])
+    assert np.linalg.norm(fin.hessian_action(k, u, q) - fin.GN_hessian_action(k, u)) < 1e-8 * np.linalg.norm(H)
