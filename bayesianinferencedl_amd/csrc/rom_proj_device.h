@@ -532,14 +532,15 @@ __device__ __forceinline__ void fused_solve_mw(const RomDev& p, d4 (&acc)[(NB * 
           const double sc = (q == qs) ? rinv : 1.0;
           D[gs] *= sc; E[gs] *= sc;
           const double rvD = __shfl(D[gs], qs * 16 + c), rvE = __shfl(E[gs], qs * 16 + c);
-          double m[4];
+          // rows below the pivot only: registers g < gs hold rows < 4 gs <= st -- nothing to fetch or update there (gs is unrolled)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const double v = __shfl(D[gs], qs * 16 + ((q + 4 * g) & 15));
-            m[g] = (q + 4 * g > st) ? v : 0.0;                            // U[st][row of this lane], rows below the pivot only
+            if (g >= gs) {
+              const double v = __shfl(D[gs], qs * 16 + ((q + 4 * g) & 15));
+              const double m = (q + 4 * g > st) ? v : 0.0;                // U[st][row of this lane]
+              D[g] = fma(-m, rvD, D[g]); E[g] = fma(-m, rvE, E[g]);      // (the source lanes of the shuffles, row st, have m = 0)
+            }
           }
-#pragma unroll
-          for (int g = 0; g < 4; ++g) { D[g] = fma(-m[g], rvD, D[g]); E[g] = fma(-m[g], rvE, E[g]); }
         }
 #pragma unroll
       for (int g = 0; g < 4; ++g) minvT[c * 16 + q + 4 * g] = E[g];        // E = M[row q + 4g][col c]
