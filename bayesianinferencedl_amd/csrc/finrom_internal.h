@@ -216,6 +216,8 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st,
                     double* w_r = nullptr, double* qoi_r = nullptr, int* cu_ticket = nullptr);
 constexpr int ROM_SPLITK_MAX_S = 64;      // batches up to this size take the split-K projection kernel (r = 49..96)
+int launch_rom_proj_wide(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                         hipStream_t st, double* w_r, double* qoi_r);
 bool rom_splitk_applies(const RomDev& p, int64_t S);
 constexpr int ROM_GRAD_SMALL_NG = 36;      // blocks per sample in rom_grad_contract_small_kernel
 int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st);

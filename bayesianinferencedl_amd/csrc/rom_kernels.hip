@@ -132,13 +132,8 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
   return 0;
 }
 
-template <int NB, int NW>
-__global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NW == 4 && NB <= 8) ? 3 : 2) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
-                                                       double* __restrict__ Ar, double* __restrict__ Br, int factor,
-                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
-                                                       const int* __restrict__ kpat) {
-  rom_proj_entry<NB, NW>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
-}
+// rom_proj_kernel<NB, NW> (rom_proj_device.h); the eight-wave instantiations (r > 144) live in rom_proj_wide.hip so that the two
+// halves compile side by side
 
 // ---------------------------------------------------------------------------------------
 // LDS-staged projection (bases up to r = 96, one wave per sample, 8 samples per workgroup).
@@ -323,7 +318,8 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
       return launch_rom_proj_single(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r, cu_ticket);
     FR_CASE(6, 1)      // (r = 81..96 through the four-wave kernel with the fused solve: 28.6 vs 27.2 ms per 100k -- 21 tiles do not split evenly)
     FR_CASE(7, 4) FR_CASE(8, 4) FR_CASE(9, 4)
-    FR_CASE(10, 8) FR_CASE(11, 8) FR_CASE(12, 8) FR_CASE(13, 8)   // r > 144: 8 waves per sample so that a wave's tiles (and its share of the fused epilogue's extra columns) fit 256 VGPRs
+    case 10: case 11: case 12: case 13: return launch_rom_proj_wide(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
+    //   // r > 144: 8 waves per sample so that a wave's tiles (and its share of the fused epilogue's extra columns) fit 256 VGPRs
     default:
       set_error("rom_proj: basis size " + std::to_string(p.r) + " > 208 not supported");
       return FINROM_ERR_UNSUPPORTED;

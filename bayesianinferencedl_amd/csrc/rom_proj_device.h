@@ -923,4 +923,12 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
 }
 
 
+template <int NB, int NW>
+__global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NW == 4 && NB <= 8) ? 3 : 2) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+                                                       double* __restrict__ Ar, double* __restrict__ Br, int factor,
+                                                       int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
+                                                       const int* __restrict__ kpat) {
+  rom_proj_entry<NB, NW>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
+}
+
 }  // namespace finrom
