@@ -1222,8 +1222,13 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
   if (!qoi_r) { if ((rc = mlp->qtmp.reserve((size_t)S * no * sizeof(double)))) return rc; qoi_r = (double*)mlp->qtmp.p; }
   if (!e_nn) { if ((rc = mlp->etmp.reserve((size_t)S * no * sizeof(double)))) return rc; e_nn = (double*)mlp->etmp.p; }
   const int64_t stride = data_per_sample ? no : 0;
-  if ((rc = launch_subfin_avg(Sop, P, m.n_in, k, S, (double*)mlp->theta.p, st))) return rc;
-  if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st))) return rc;
+  // (the sub-fin averages theta = S k are formed inside the network's forward kernel: it reads k anyway)
+  if (P <= 16) {
+    if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st, Sop, P, (double*)mlp->theta.p))) return rc;
+  } else {
+    if ((rc = launch_subfin_avg(Sop, P, m.n_in, k, S, (double*)mlp->theta.p, st))) return rc;
+    if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st))) return rc;
+  }
   if ((rc = finrom_rom_grad(rom, (const double*)mlp->theta.p, (const double*)mlp->shift.p, 1, S, loss, (double*)mlp->gth.p, nullptr,
                             qoi_r, info, st))) return rc;
   return launch_mlp_backward(m, S, (const float*)mlp->tape.p, data, stride, qoi_r, e_nn, (const double*)mlp->gth.p, Sop, P, grad, st);

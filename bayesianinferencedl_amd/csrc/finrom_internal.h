@@ -152,7 +152,8 @@ struct MlpDev {
   const float* Wh; const float* bh;            // [n_w x n_out], [n_out]
 };
 int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double* data, int64_t data_stride, float* tape,
-                       double* e_out, double* data_shift, hipStream_t st);
+                       double* e_out, double* data_shift, hipStream_t st, const double* Sop = nullptr, int P = 0,
+                       double* theta_out = nullptr);
 int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
                         const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st);
 

@@ -19,23 +19,56 @@ constexpr int MLP_MAX_W = 64;        // hidden width (reference: 50 / 100 -> 64 
 constexpr int MLP_PARTS = 4;         // threads per hidden unit in the first layer (256 threads = 64 units x 4 parts)
 
 // e_out[s][o] (double) = network output; data_shift[s][o] = data[o] - e_out (what the ROM adjoint is run against)
+// (Sop, P, theta_out: when given, the sub-fin averages theta = S k of the same field (fom/forward_solve.py:466-480) are formed here
+// in fp64 while k is being read anyway -- one launch less in the one-sample call chain of finrom_romml_grad)
 __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev m, const double* __restrict__ k, int64_t S,
                                                           const double* __restrict__ data, int64_t data_stride,
                                                           float* __restrict__ tape, double* __restrict__ e_out,
-                                                          double* __restrict__ data_shift) {
+                                                          double* __restrict__ data_shift, const double* __restrict__ Sop, int P,
+                                                          double* __restrict__ theta_out) {
   extern __shared__ float xs[];                        // [n_in] input, then scratch
   __shared__ float part[MLP_PARTS][MLP_MAX_W];
   __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
+  __shared__ double tred[4][16];
   const int64_t s = blockIdx.x;
   const int tid = threadIdx.x, nw = m.n_w;
-  for (int i = tid; i < m.n_in; i += 256) xs[i] = (float)k[s * m.n_in + i];
+  double th[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) th[p] = 0.0;
+  for (int i = tid; i < m.n_in; i += 256) {
+    const double kv = k[s * m.n_in + i];
+    xs[i] = (float)kv;
+    if (theta_out != nullptr) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) if (p < P) th[p] = fma(Sop[(int64_t)p * m.n_in + i], kv, th[p]);
+    }
+  }
+  if (theta_out != nullptr) {                          // wave reduction, then the four waves in order
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      double v = th[p];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if ((tid & 63) == 0) tred[tid >> 6][p] = v;
+    }
+  }
   __syncthreads();
+  if (theta_out != nullptr && tid < P) theta_out[s * P + tid] = (tred[0][tid] + tred[1][tid]) + (tred[2][tid] + tred[3][tid]);
   {                                                   // y0 = W0^T x + b0: unit j = tid % 64, part p = tid / 64 of the rows
     const int j = tid & 63, p = tid >> 6;
     float acc = 0.f;
     if (j < nw) {
       const int i0 = (int)((int64_t)m.n_in * p / MLP_PARTS), i1 = (int)((int64_t)m.n_in * (p + 1) / MLP_PARTS);
-      for (int i = i0; i < i1; ++i) acc = fmaf(xs[i], m.W0[(int64_t)i * nw + j], acc);
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};              // four independent chains, eight loads in flight each
+      int i = i0;
+      for (; i + 32 <= i1; i += 32) {
+        float wv[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) wv[u] = m.W0[(int64_t)(i + u) * nw + j];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) a4[u & 3] = fmaf(xs[i + u], wv[u], a4[u & 3]);
+      }
+      for (; i < i1; ++i) a4[0] = fmaf(xs[i], m.W0[(int64_t)i * nw + j], a4[0]);
+      acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     part[p][j] = acc;
   }
@@ -102,7 +135,20 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpDev m, int64_t S, 
   }
   for (int i = tid; i < m.n_in; i += 256) {
     float acc = 0.f;
-    for (int j = 0; j < nw; ++j) acc = fmaf(g[j], m.W0[(int64_t)i * nw + j], acc);
+    {
+      const float* __restrict__ wrow = m.W0 + (int64_t)i * nw;
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      int j = 0;
+      for (; j + 16 <= nw; j += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = wrow[j + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a4[u & 3] = fmaf(g[j + u], wv[u], a4[u & 3]);
+      }
+      for (; j < nw; ++j) a4[0] = fmaf(g[j], wrow[j], a4[0]);
+      acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    }
     double out = -(double)acc;                         // d loss / d input = -vjp(r)
     for (int p = 0; p < P; ++p) out = fma(gth[p], Sop[(int64_t)p * m.n_in + i], out);
     grad[s * m.n_in + i] = out;
@@ -110,11 +156,12 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpDev m, int64_t S, 
 }
 
 int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double* data, int64_t data_stride, float* tape,
-                       double* e_out, double* data_shift, hipStream_t st) {
+                       double* e_out, double* data_shift, hipStream_t st, const double* Sop, int P, double* theta_out) {
   if (S == 0) return 0;
+  if (theta_out != nullptr && (P < 1 || P > 16)) { set_error("mlp_forward: at most 16 sub-fin averages"); return FINROM_ERR_UNSUPPORTED; }
   ScopedKernelTimer t(K_MISC, st);
   hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)S), dim3(256), (size_t)m.n_in * sizeof(float), st, m, k, S, data, data_stride,
-                     tape, e_out, data_shift);
+                     tape, e_out, data_shift, Sop, P, theta_out);
   FR_HIP(hipGetLastError());
   return 0;
 }
