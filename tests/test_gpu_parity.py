@@ -610,3 +610,19 @@ def test_hessian_action_matches_differences_of_the_device_gradient(spaces):
     assert np.linalg.norm(H - fd) < 1e-6 * np.linalg.norm(fd)
     q = fin.qoi_operator(fin.forward(k)[0])
     assert np.linalg.norm(fin.hessian_action(k, u, q) - fin.GN_hessian_action(k, u)) < 1e-8 * np.linalg.norm(H)
+
+
+@pytest.mark.parametrize("r", [120, 200])
+def test_wide_basis_fused_qoi_with_forty_observations(problems, spaces, r):
+    """The QoI-only path of bases wider than 96 carries [B_r | (B_obs Phi)^T] as extra tile columns: 1 + n_obs = 41 columns are
+    three tile columns (the default observation operator has nine: one).  Same numbers as the path that returns w_r."""
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    prob = problems(12); V = spaces(12)
+    rom = AffineROMFin(V, None, oracle_basis(prob, r), external_obs=True)
+    assert rom.n_obs == 40
+    TH = np.random.default_rng(8).uniform(0.1, 3.5, (130, 9))
+    full = rom.forward_nine_param_reduced_batch(TH)
+    qonly = rom.forward_nine_param_reduced_batch(TH, want_w=False)
+    assert (full["info"] == 0).all() and (qonly["info"] == 0).all()
+    assert rel(qonly["qoi_r"], full["qoi_r"]) < TOL
+    assert rel(full["qoi_r"], full["w_r"] @ rom.B_obs_phi.T) < TOL
