@@ -68,7 +68,9 @@ struct PostTables {
 };
 
 // ---- forward: factorisation fused with L y = F over one segment ----------------------------------------------------------
-template <int NS, bool POST, int NXM>
+// (PF: the right-hand side of the entering node travels with its three matrix entries -- for callers that run one wave per SIMD
+// or less, where nothing else hides the load; the m <= 12 kernel is HBM-bound and keeps its register budget)
+template <int NS, bool POST, int NXM, bool PF = false>
 __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, double* __restrict__ xs, const double* __restrict__ Fg,
                                            const int* __restrict__ abmap, const PostTables& T, int g0, int e0, int npiv, int ntot, int L0,
                                            double (&win)[NS * (NS + 1) / 2], double (&yw)[NS], int& bad) {
@@ -79,7 +81,7 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
   if constexpr (POST) static_for<0, L::SIZE>([&](auto i) { xs[decltype(i)::value * 64] = 0.0; });
 
   // node t enters the window in slot u = t mod NS (the slot its predecessor t - NS has just left)
-  auto enter = [&](auto uc, int t, double ab0, double ab1, double ab2) {
+  auto enter = [&](auto uc, int t, double ab0, double ab1, double ab2, double fpre = 0.0) {
     constexpr int u = decltype(uc)::value;
     static_for<0, NS>([&](auto vc) { constexpr int v = decltype(vc)::value; if constexpr (v != u) win[tri(u, v)] = 0.0; });
     double diag = 0.0, yv = 0.0;
@@ -109,7 +111,7 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
     win[tri(u, u)] = diag + ab0;
     win[tri(u, (u + NS - 1) % NS)] += ab1;               // previous node (zero entry where there is none)
     win[tri(u, (u + 1) % NS)] += ab2;                    // the node B positions back
-    yw[u] = yv + Fg[g0 + t];
+    yw[u] = yv + (PF ? fpre : Fg[g0 + t]);
     if constexpr (POST) {
       for (int c = T.ecp_ptr[t], c1 = T.ecp_ptr[t + 1]; c < c1; ++c)       // long-range couplings of this node: to extras
         xs[(L::X + T.ecp_slot[c] * NS + u) * 64] += io.ld(T.ecp_off[c]);
@@ -120,7 +122,7 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
     constexpr int u = decltype(uc)::value;
     if (u < ntot) {
       const int g = 3 * (g0 + u);
-      enter(uc, u, io.ld(abmap[g]), io.ld(abmap[g + 1]), io.ld(abmap[g + 2]));
+      enter(uc, u, io.ld(abmap[g]), io.ld(abmap[g + 1]), io.ld(abmap[g + 2]), PF ? Fg[g0 + u] : 0.0);
     }
   });
 
@@ -129,6 +131,7 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
   // divides NS, so with the loop unrolled NS times ring slot and window slot are both compile-time constants.
   constexpr int RF = (NS % 2 == 0) ? 2 : NS;
   double ab[RF][3];
+  double abf[PF ? RF : 1];
   static_for<0, RF>([&](auto i) { ab[decltype(i)::value][0] = ab[decltype(i)::value][1] = ab[decltype(i)::value][2] = 0.0; });
   for (int s0 = 0; s0 < npiv + RF; s0 += NS) {
     static_for<0, NS>([&](auto usc) {
@@ -190,12 +193,13 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
             });
           }
         }
-        if (more) enter(std::integral_constant<int, u>{}, pp + NS, ab0, ab1, ab2);
+        if (more) enter(std::integral_constant<int, u>{}, pp + NS, ab0, ab1, ab2, PF ? abf[PF ? rs : 0] : 0.0);
         else static_for<0, NS>([&](auto vc) { win[tri(u, decltype(vc)::value)] = 0.0; });      // nobody enters: the slot is empty
       }
       if (sidx < npiv && sidx + NS < ntot) {             // entries of the node that enters after pivot s: in flight for RF steps
         const int g = 3 * (g0 + sidx + NS);      // (physical slots: entries with the same affine record share one)
         ab[rs][0] = io.ld(abmap[g]); ab[rs][1] = io.ld(abmap[g + 1]); ab[rs][2] = io.ld(abmap[g + 2]);
+        if constexpr (PF) abf[rs] = Fg[g0 + sidx + NS];
       }
     });
   }
@@ -876,7 +880,7 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
     double win[NSF * (NSF + 1) / 2], yw[NSF];
     for (int f = wv; f < p.nfins; f += WV) {
       const int npiv = p.npf, ntot = p.npf + p.nif;
-      band_sweep<NSF, false, NXM>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      band_sweep<NSF, false, NXM, true>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
       int k = 0;
       for (int t = 0; t < p.nif; ++t)
         for (int s = 0; s <= t; ++s, ++k) {
