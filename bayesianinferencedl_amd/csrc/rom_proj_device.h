@@ -336,19 +336,35 @@ __device__ __forceinline__ void proj_main_uniform(const RomDev& p, const int* __
 //     gap 4   scalar loads: thetas of k-step ks + 4, record of k-step ks + 5
 //   s_waitcnt lgkmcnt(0); s_barrier      (NOT __syncthreads(): that would also wait for the table loads just issued)
 // ---------------------------------------------------------------------------------------
+// Which wave builds which 16-column block of the slab.  The block triangle's NT tiles do not always divide by NW (r = 200: 91
+// tiles over 8 waves = 3 x 12 + 5 x 11), and every wave waits for the slowest at the k-step's barrier: when the waves with one
+// tile less can take ALL the slab building (<= 3 blocks each; a block costs about as much pipe time as a third of an MFMA), they
+// do, and the waves with the extra tile build nothing.  Otherwise blocks go round robin (block b -> wave b % NW) as before.
+template <int NB, int NW> struct SlabOwner {
+  static constexpr int NT = NB * (NB + 1) / 2;
+  static constexpr int tiles(int w) { return (NT - w + NW - 1) / NW; }
+  static constexpr int nlight() { int n = 0; for (int w = 0; w < NW; ++w) n += tiles(w) == tiles(NW - 1); return n; }
+  static constexpr bool light_only() { return NW == 8 && nlight() < NW && (NB + nlight() - 1) / nlight() <= 3; }      // (measured: r = 200 -2.5 %, r = 170 -1.4 %; with four waves, r = 136, +1.6 %: round robin there)
+  static constexpr int owner(int b) { return light_only() ? NW - nlight() + b % nlight() : b % NW; }      // (light waves = the last nlight())
+  static constexpr int count(int w) { int n = 0; for (int b = 0; b < NB; ++b) n += owner(b) == w; return n; }
+  static constexpr int block(int w, int j) { for (int b = 0; b < NB; ++b) if (owner(b) == w && j-- == 0) return b; return 0; }
+};
+
 template <int NB, int NW, int W>
 __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int* __restrict__ kmeta_g,
                                                      const double* __restrict__ theta_g, int q, int c, int lane, double* slab,
                                                      d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
   constexpr int NT = NB * (NB + 1) / 2;
   constexpr int MINE = (NT - W + NW - 1) / NW;           // tiles of this wave
-  constexpr int NOWN = (NB - W + NW - 1) / NW;           // slab blocks of this wave
+  using SO = SlabOwner<NB, NW>;
+  constexpr int NOWN0 = SO::count(W);                   // slab blocks of this wave (may be none)
+  constexpr int NOWN = NOWN0 > 0 ? NOWN0 : 1;            // (array extents)
   static_assert(MINE >= 5, "five gaps are used");
   typedef const i4 __attribute__((address_space(4)))* c_i4_p;
   const c_i4_p kmeta = (c_i4_p)(unsigned long long)kmeta_g;
   const c_f64_p theta_s = (c_f64_p)(unsigned long long)theta_g;
   const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.tvu), 0, p.tvu_bytes, 0x00020000);
-  const int voff = (q * p.rp + c + 16 * W) * 8;
+  const int voff = (q * p.rp + c) * 8;
   const int rowb = 4 * p.rp * 8;
   auto theta_of = [&](int pp) -> double { return pp == 0 ? 1.0 : theta_s[pp - 1]; };
   auto thetas = [&](double (&th)[ROM_MAX_NT], const i4& k) { sfor<0, ROM_MAX_NT>([&](auto tc) { th[decltype(tc)::value] = theta_of(k[decltype(tc)::value]); }); };
@@ -356,9 +372,9 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
     constexpr int t = decltype(tc)::value;
     if (t < nt) {
       asm volatile("" ::: "memory");
-      sfor<0, NOWN>([&](auto jc) {
+      sfor<0, NOWN0>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        raw[t][j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * NW * j, (slot + t) * rowb, 0));
+        raw[t][j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * SO::block(W, j), (slot + t) * rowb, 0));
       });
     }
   };
@@ -366,21 +382,21 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
   // own blocks of one slab -> LDS buffer at (double) offset o
   auto build_store = [&](const double (&raw)[ROM_MAX_NT][NOWN], const double (&th)[ROM_MAX_NT], int nt, int o) {
     double own[NOWN];
-    sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = th[0] * raw[0][j]; });
+    sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = th[0] * raw[0][j]; });
     sfor<1, ROM_MAX_NT>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       if (t < nt) {
         asm volatile("" ::: "memory");
-        sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = fma(th[t], raw[t][j], own[j]); });
+        sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = fma(th[t], raw[t][j], own[j]); });
       }
     });
-    sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; slab[o + (W + j * NW) * 64 + lane] = own[j]; });
+    sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; slab[o + SO::block(W, j) * 64 + lane] = own[j]; });
   };
   auto read_slab = [&](double (&v)[NB], int o) { sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; v[b] = slab[o + b * 64 + lane]; }); };
   auto exchange = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   double rawa[ROM_MAX_NT][NOWN], rawb[ROM_MAX_NT][NOWN], thB[ROM_MAX_NT], thN[ROM_MAX_NT], va[NB], vb[NB];
-  sfor<0, ROM_MAX_NT>([&](auto tc) { sfor<0, NOWN>([&](auto jc) { rawa[decltype(tc)::value][decltype(jc)::value] = 0.0; rawb[decltype(tc)::value][decltype(jc)::value] = 0.0; }); });
+  sfor<0, ROM_MAX_NT>([&](auto tc) { sfor<0, NOWN0>([&](auto jc) { rawa[decltype(tc)::value][decltype(jc)::value] = 0.0; rawb[decltype(tc)::value][decltype(jc)::value] = 0.0; }); });
   // prologue: slabs 0 and 1 into LDS, va <- slab 0, raw buffers <- k-steps 2 and 3, scalars up to k-step 4
   constexpr int SL = NB * 64;
   int o0 = 0, o1 = SL, o2 = 2 * SL;
@@ -413,20 +429,20 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
       if constexpr (i == 0) read_slab(vn, o1);
       if constexpr (i == 1) {
         double own[NOWN];
-        sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = thB[0] * raw[0][j]; });
+        sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = thB[0] * raw[0][j]; });
         sfor<1, NTS>([&](auto tc) {
           constexpr int t = decltype(tc)::value;
-          sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = fma(thB[t], raw[t][j], own[j]); });
+          sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = fma(thB[t], raw[t][j], own[j]); });
         });
-        sfor<0, NOWN>([&](auto jc) { constexpr int j = decltype(jc)::value; slab[o2 + (W + j * NW) * 64 + lane] = own[j]; });
+        sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; slab[o2 + SO::block(W, j) * 64 + lane] = own[j]; });
       }
       if constexpr (i == 2 || i == 3) {
         sfor<(i - 2) * 2, (i - 2) * 2 + 2>([&](auto tc) {
           constexpr int t = decltype(tc)::value;
           if constexpr (t < NTS)
-            sfor<0, NOWN>([&](auto jc) {
+            sfor<0, NOWN0>([&](auto jc) {
               constexpr int j = decltype(jc)::value;
-              raw[t][j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * NW * j, (m4[0] + t) * rowb, 0));
+              raw[t][j] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * SO::block(W, j), (m4[0] + t) * rowb, 0));
             });
         });
       }

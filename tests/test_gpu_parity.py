@@ -68,7 +68,7 @@ def test_fom_param_parity(problems, spaces, params, dim):
     assert rel(res["qoi"][:16], W @ fo.B_obs.T) < TOL
 
 
-@pytest.mark.parametrize("m,r", [(4, 8), (12, 80), (12, 81), (12, 96), (12, 33), (12, 100), (12, 120), (12, 136), (12, 160), (12, 200), (4, 150)])
+@pytest.mark.parametrize("m,r", [(4, 8), (12, 80), (12, 81), (12, 96), (12, 33), (12, 100), (12, 120), (12, 136), (12, 160), (12, 170), (12, 200), (4, 150)])
 def test_rom_parity(problems, spaces, m, r):
     from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
     prob = problems(m); V = spaces(m)
