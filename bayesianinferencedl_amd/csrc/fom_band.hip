@@ -852,6 +852,121 @@ __global__ __launch_bounds__(64) void fom_band_lds_kernel(BandDev p, const int* 
     for (int i = 0; i < 4 && i < p.n_obs; ++i) qoi[i] = (double)(tk[i + 1] - tk[i]);
 }
 
+// ---- the post's backward sweep with the other waves as loaders ----------------------------------------------------------------
+// L^T w = y is a recurrence over the pivots: one wave computes, and what it waits for is the next column of L from HBM (written
+// non-temporally by the forward sweep; a register ring of four columns left 0.9 us per pivot at one wave per CU).  The window is
+// dead by now, so LDS holds two buffers of CB columns (NS + 1 doubles per lane each: l_1..l_B, 1/L_jj, y_j): while wave 0
+// substitutes chunk k out of one, the waves 1 .. WV-1 deposit chunk k - 1 into the other, from registers they requested DL chunk
+// steps earlier (HBM latency under load is several steps); one `s_waitcnt lgkmcnt(0); s_barrier` per chunk -- not
+// __syncthreads(), whose vmcnt(0) would drain the loaders' pipeline.  The pivot's table entries and its couplings to the extras
+// stay with wave 0 (register ring, requested RT pivots ahead, their scalars three more): 1.54 -> 1.09 ms per 16k samples at m = 20.
+// What is left is mostly those scalar loads: they share lgkmcnt with the LDS reads, so every wait for an LDS value also waits
+// for them; shipping them through LDS as well (complete pivot records built by the loaders) made the LOADERS wait for them
+// instead (2.8 ms).
+template <int NS, int NXM, int WV, int WVI>
+__device__ __forceinline__ void band_bsweep_ldsw(const BandDev& p, const Io& io, double* __restrict__ xs, const PostTables& T, int e0,
+                                                 int npiv, int L0) {
+  constexpr int CB = 6, COLS = NS + 1, BUF = CB * COLS, WXO = 2 * BUF;       // LDS (doubles per lane): 2 x CB x (NS + 1) | WX[NXM]
+  constexpr int U = NS / gcd_c(NS, CB) * CB;                                   // unroll: window slots and chunk positions compile-time
+  constexpr int NP = WV - 1;                                                   // loader waves
+  static_assert(WV >= 2 && (2 * BUF + NXM) * 512 <= 160 * 1024, "ring fits LDS (launch_ldsw sizes the allocation)");
+  const int kmax = (npiv - 1) / CB;
+  auto exchange = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  constexpr int MINE = WVI > 0 ? (CB - (WVI - 1) + NP - 1) / NP : 0;      // columns of a chunk this loader fetches: i = WVI - 1 + j NP
+  constexpr int MA = MINE > 0 ? MINE : 1;
+  auto fetch = [&](int k, double (&col)[MA][COLS]) {     // request the own columns of chunk k (nothing is waited for here)
+    static_for<0, MINE>([&](auto jc) {
+      constexpr int j = decltype(jc)::value, i = WVI - 1 + j * NP;
+      const int v = k * CB + i;
+      if (k >= 0 && v < npiv) {
+        const int base = p.offL + L0 + v * NS;
+        static_for<0, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; col[j][s_] = io.template ldk<s_>(base); });
+        col[j][NS] = io.ld(p.offY + e0 + v);
+      }
+    });
+  };
+  auto deposit = [&](int k, int par, const double (&col)[MA][COLS]) {
+    static_for<0, MINE>([&](auto jc) {
+      constexpr int j = decltype(jc)::value, i = WVI - 1 + j * NP;
+      if (k >= 0 && k * CB + i < npiv)
+        static_for<0, COLS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; xs[(par * BUF + i * COLS + s_) * 64] = col[j][s_]; });
+    });
+  };
+  if constexpr (WVI == 0) static_for<0, NXM>([&](auto sc) { xs[(WXO + decltype(sc)::value) * 64] = 0.0; });
+  if constexpr (WVI > 0) {
+    constexpr int DL = 4;
+    double cs[DL][MA][COLS];
+    static_for<0, DL>([&](auto dc) { constexpr int d = decltype(dc)::value; fetch(kmax - d, cs[d]); });
+    deposit(kmax, 0, cs[0]);
+    fetch(kmax - DL, cs[0]);
+    exchange();
+    // step for chunk k: deposit chunk k - 1 (set (kmax - k + 1) % DL), refill that set with chunk k - 1 - DL
+    for (int k = kmax; k >= 0; k -= DL) {
+      static_for<0, DL>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if (k - d >= 0) {
+          constexpr int si = (d + 1) % DL;
+          deposit(k - d - 1, (kmax - (k - d - 1)) & 1, cs[si]);
+          fetch(k - d - 1 - DL, cs[si]);
+          exchange();
+        }
+      });
+    }
+  } else {
+    exchange();                                          // chunk kmax is in buffer 0
+    double ww[NS];
+    static_for<0, NS>([&](auto i) { ww[decltype(i)::value] = 0.0; });
+    // (a pivot takes ~0.6 us here: the couplings are requested RT = 6 pivots ahead, the scalars they depend on three more)
+    constexpr int RT = 6;
+    double lxv[RT][NXM];
+    int am_r[RT], ex_r[RT];
+    struct Q { int am, k, ex; };
+    // (raw table entries only: any arithmetic on them here would wait for the scalar loads where they are issued)
+    auto tables = [&](int q) -> Q { Q r{0, 0, 0}; if (q >= 0 && q < npiv) { r.am = T.act[q]; r.k = T.lx_ptr[q]; r.ex = T.ent_extra[q]; } return r; };
+    auto request = [&](auto rc, const Q& t) {             // pivot whose tables are t -> ring slot rc
+      constexpr int rs = decltype(rc)::value;
+      am_r[rs] = t.am; ex_r[rs] = t.ex;
+      if (t.am != 0) {
+        int k = p.offLx + t.k;
+        static_for<0, NXM>([&](auto sc) { constexpr int sl = decltype(sc)::value; if (t.am & (1 << sl)) { lxv[rs][sl] = io.ld(k); ++k; } });
+      }
+    };
+    constexpr int UT = U / gcd_c(U, RT) * RT;             // (the table ring's slot is compile-time too)
+    const int vtop = npiv - 1 + RT;
+    Q q1 = tables(vtop - RT), q2 = tables(vtop - RT - 1), q3 = tables(vtop - RT - 2);
+    for (int p0 = vtop / UT * UT; p0 >= 0; p0 -= UT) {
+      static_for<0, UT>([&](auto rc) {
+        constexpr int uu = UT - 1 - decltype(rc)::value;
+        constexpr int u = uu % NS, rs = uu % RT, ci = uu % CB;
+        const int v = p0 + uu;
+        if (v <= vtop) {
+          if (v < npiv) {
+            const int par = (kmax - v / CB) & 1;
+            const double* col = xs + (par * BUF + ci * COLS) * 64;
+            double acc = col[NS * 64];
+            static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; acc = fma(-col[(s_ - 1) * 64], ww[(u + s_) % NS], acc); });
+            const int am = am_r[rs];
+            if (am != 0)
+              static_for<0, NXM>([&](auto sc) {
+                constexpr int sl = decltype(sc)::value;
+                if (am & (1 << sl)) acc = fma(-lxv[rs][sl], xs[(WXO + sl) * 64], acc);
+              });
+            const double wv = acc * col[(NS - 1) * 64];
+            io.st(wv, p.offY + e0 + v);
+            ww[u] = wv;
+            const int ex = ex_r[rs];
+            if (ex != 0) xs[(WXO + ex - 1) * 64] = wv;
+            if constexpr (ci == 0) exchange();            // chunk v / CB is done: the loaders have filled the other buffer
+          }
+          const int nx = v - RT;
+          if (nx >= 0 && nx < npiv) request(std::integral_constant<int, rs>{}, q1);
+          q1 = q2; q2 = q3; q3 = tables(nx - 3);
+        }
+      });
+    }
+  }
+}
+
 // WV waves per 64 samples: the eight fins are independent (shared over the waves), the post's forward sweep is band_sweep_ldsw,
 // its backward sweep runs on wave 0 with a deeper column ring
 template <int NSF, int NSP, int NXM, int WV>
@@ -907,7 +1022,11 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
     bad |= badp;
   }
   tk[2] = wall_clock64();
-  if (wv == 0) band_bsweep<NSP, true, NXM, (NSP <= 14 ? 2 : 4)>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
+  {
+#define FR_W(I) case I: if constexpr (I < WV) band_bsweep_ldsw<NSP, NXM, WV, I>(p, io, xs, T, p.post_e0, p.npost, p.post_L0); break;
+    switch (wv) { FR_W(0) FR_W(1) FR_W(2) FR_W(3) default: break; }
+#undef FR_W
+  }
   __syncthreads();
   tk[3] = wall_clock64();
   for (int f = wv; f < p.nfins; f += WV)
@@ -960,7 +1079,7 @@ int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* q
   constexpr int WV = 4;
   static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
   constexpr size_t lds_w = (size_t)((NSP - 1) * NSP / 2 + 2 * (NSP + 1) + NSP + 1) * 64 * sizeof(double);      // window | 2 x row B | y | flag
-  constexpr size_t lds_b = (size_t)(XL<NSP, NXM>::WX + NXM) * 64 * sizeof(double);
+  constexpr size_t lds_b = (size_t)(2 * 6 * (NSP + 1) + NXM) * 64 * sizeof(double);      // backward: two buffers of six columns + WX
   constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
   static_assert(lds <= 160 * 1024, "LDS window");
   static bool once = false;
