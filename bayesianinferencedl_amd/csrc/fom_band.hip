@@ -432,7 +432,9 @@ __device__ __forceinline__ void band_sweep_ldsw(const BandDev& p, const Io& io, 
   auto xst = [&](double v, int idx) { io.st(v, offX + idx); };
   // window entry (a, b), a >= b, of the pivot whose row-B buffer is `par`
   auto widx = [](int a, int b, int par) constexpr { return a < B ? tri(a, b) : TB + par * RS + b; };
-  auto barrier = [&]() { __syncthreads(); };
+  // LDS-only barrier: nothing a wave stores to the workspace inside this sweep is read by another wave before the sweep ends
+  // (the caller's __syncthreads()), and __syncthreads() here would make every pivot wait for the column stores' acknowledgements
+  auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
   // node t (renamed slot u) enters at position P of the window whose row-B buffer is `par` (wave E only)
   auto enter = [&](auto pc, auto parc, int t, int u, double ab0, double ab1, double ab2, int ex, int c0, int c1, double ft) {
@@ -1021,6 +1023,7 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
 #undef FR_W
     bad |= badp;
   }
+  __syncthreads();                                       // the columns of L, y and the extras' couplings are in the workspace
   tk[2] = wall_clock64();
   {
 #define FR_W(I) case I: if constexpr (I < WV) band_bsweep_ldsw<NSP, NXM, WV, I>(p, io, xs, T, p.post_e0, p.npost, p.post_L0); break;
