@@ -520,7 +520,6 @@ __device__ __forceinline__ void band_sweep_ldsw(const BandDev& p, const Io& io, 
     constexpr int par = decltype(parc)::value;
     Tab nxt{0, 0, 0, 0, 0, 0.0};
     int giD[3] = {0, 0, 0};
-    if constexpr (WVI == E) { nxt = tables(pp + 1); slots(pp + 3, giD); }
     const double d = wl[0];
     if (!(d > 0.0)) bad = 1;
     double inv = __builtin_amdgcn_rsq(d);
@@ -555,6 +554,9 @@ __device__ __forceinline__ void band_sweep_ldsw(const BandDev& p, const Io& io, 
         });
       }
     });
+    // the scalar loads of the next pivots' table entries go HERE, behind this wave's last LDS read of the pivot: they share
+    // lgkmcnt with LDS and return out of order, so the next wait for an LDS value also waits for them -- now the barrier's
+    if constexpr (WVI == E) { nxt = tables(pp + 1); slots(pp + 3, giD); }
     if constexpr (WVI == E) {
       // extras with a non-zero coupling to this pivot, one after the other (requesting the rows of four of them together was not
       // faster here either: 5.36 vs 5.24 ms)
