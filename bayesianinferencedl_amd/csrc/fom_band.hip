@@ -132,6 +132,11 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
   constexpr int RF = (NS % 2 == 0) ? 2 : NS;
   double ab[RF][3];
   double abf[PF ? RF : 1];
+  int gq[3] = {0, 0, 0};                                 // PF: slot numbers / right-hand side for the NEXT step's requests
+  double fq = 0.0;
+  if constexpr (PF) {
+    if (0 < npiv && NS < ntot) { const int g = 3 * (g0 + NS); gq[0] = abmap[g]; gq[1] = abmap[g + 1]; gq[2] = abmap[g + 2]; fq = Fg[g0 + NS]; }
+  }
   static_for<0, RF>([&](auto i) { ab[decltype(i)::value][0] = ab[decltype(i)::value][1] = ab[decltype(i)::value][2] = 0.0; });
   for (int s0 = 0; s0 < npiv + RF; s0 += NS) {
     static_for<0, NS>([&](auto usc) {
@@ -198,8 +203,18 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
       }
       if (sidx < npiv && sidx + NS < ntot) {             // entries of the node that enters after pivot s: in flight for RF steps
         const int g = 3 * (g0 + sidx + NS);      // (physical slots: entries with the same affine record share one)
-        ab[rs][0] = io.ld(abmap[g]); ab[rs][1] = io.ld(abmap[g + 1]); ab[rs][2] = io.ld(abmap[g + 2]);
-        if constexpr (PF) abf[rs] = Fg[g0 + sidx + NS];
+        if constexpr (PF) {                      // slot numbers and right-hand side were requested a step ago
+          ab[rs][0] = io.ld(gq[0]); ab[rs][1] = io.ld(gq[1]); ab[rs][2] = io.ld(gq[2]);
+          abf[rs] = fq;
+        } else {
+          ab[rs][0] = io.ld(abmap[g]); ab[rs][1] = io.ld(abmap[g + 1]); ab[rs][2] = io.ld(abmap[g + 2]);
+        }
+      }
+      if constexpr (PF) {
+        if (sidx + 1 < npiv && sidx + 1 + NS < ntot) {
+          const int g = 3 * (g0 + sidx + 1 + NS);
+          gq[0] = abmap[g]; gq[1] = abmap[g + 1]; gq[2] = abmap[g + 2]; fq = Fg[g0 + sidx + 1 + NS];
+        }
       }
     });
   }
