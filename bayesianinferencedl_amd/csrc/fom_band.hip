@@ -652,17 +652,18 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
                                                 const int* __restrict__ abmap, const PostTables& T, int g0, int e0, int npiv, int ntot,
                                                 int L0, int& bad) {
   constexpr int B = NS - 1, RS = NS + 1;
-  constexpr int TF = NS * (NS + 1) / 2, YP = TF;          // prologue only: the full triangle | y of the first NS nodes
-  constexpr int COL = 0, ROWB = 2 * RS;                   // steady state (aliases the triangle): COL[par][s | y_0], ROWB[par][k | y_B]
+  constexpr int COL = 0, ROWB = 2 * RS, XOFF = 4 * RS;    // LDS (doubles per lane): COL[par][s | y_0] | ROWB[par][k | y_B] | the extras' state
   constexpr int ST = 0, YU = 1 % WV, E = WV - 1;
   using L = XL<NS, NXM>;
-  const int offX = p.offX;
-  auto xld = [&](int idx) -> double { return io.ld(offX + idx); };
-  auto xst = [&](double v, int idx) { io.st(v, offX + idx); };
+  // the extras' state (wave E only) sits in LDS now that the window has left it: a row update is ~50 LDS operations instead of
+  // a round trip to L2 per extra
+  auto xld = [&](int idx) -> double { return wl[(XOFF + idx) * 64]; };
+  auto xst = [&](double v, int idx) { wl[(XOFF + idx) * 64] = v; };
   // LDS-only barrier: nothing a wave stores to the workspace inside this sweep is read by another wave before the sweep ends
   // (the caller's __syncthreads()), and __syncthreads() here would make every pivot wait for the column stores' acknowledgements
   auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
+  double corner = 0.0;                                   // window entry (B, 0) of the first pivot (wave E)
   // node t (renamed slot u) enters at position P of the window whose row-B buffer is `par` (wave E only)
   auto enter = [&](auto pc, auto parc, auto proc, int t, int u, double ab0, double ab1, double ab2, int ex, int c0, int c1, double ft) {
     constexpr int P = decltype(pc)::value, par = decltype(parc)::value;
@@ -698,16 +699,11 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
     }
     if constexpr (P >= 1) row[P - 1] += ab1;
     if constexpr (P == B) row[0] += ab2;
-    if constexpr (PRO) {
-      static_for<0, P>([&](auto kc) { constexpr int k = decltype(kc)::value; wl[tri(P, k) * 64] = row[k]; });
-      wl[tri(P, P) * 64] = diag + ab0;
-      wl[(YP + P) * 64] = yv + ft;
-    } else {
-      static_for<0, P>([&](auto kc) { constexpr int k = decltype(kc)::value; wl[(ROWB + par * RS + k) * 64] = row[k]; });
-      wl[(ROWB + par * RS + P) * 64] = diag + ab0;
-      wl[(ROWB + par * RS + NS) * 64] = yv + ft;
-      wl[(COL + par * RS + B) * 64] = row[0];               // its coupling to the next pivot: the last entry of that pivot's column
-    }
+    static_for<0, P>([&](auto kc) { constexpr int k = decltype(kc)::value; wl[(ROWB + par * RS + k) * 64] = row[k]; });
+    wl[(ROWB + par * RS + P) * 64] = diag + ab0;
+    wl[(ROWB + par * RS + NS) * 64] = yv + ft;
+    if constexpr (!PRO) wl[(COL + par * RS + B) * 64] = row[0];      // its coupling to the next pivot: the last entry of that pivot's column
+    if constexpr (PRO && P == B) corner = row[0];
     for (int c = c0; c < c1; ++c) {
       const int idx = L::X + T.ecp_slot[c] * NS + u;
       xst(xld(idx) + io.ld(T.ecp_off[c]), idx);
@@ -732,51 +728,49 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
   double abA[3] = {0.0, 0.0, 0.0}, abB[3] = {0.0, 0.0, 0.0};
   int giC[3] = {0, 0, 0};
   Tab cur{0, 0, 0, 0, 0, 0.0};
-  if constexpr (WVI == E) {                              // prologue: empty window, the first NS nodes, the pipelines
-    static_for<0, TF + NS>([&](auto i) { wl[decltype(i)::value * 64] = 0.0; });
-    for (int i = 0; i < L::SIZE; ++i) xst(0.0, i);
-    static_for<0, NS>([&](auto pc) {
-      constexpr int P = decltype(pc)::value;
+  // prologue: the first NS nodes enter one at a time; wave E forms the node's row (through the same buffer the main loop uses),
+  // the owners of the diagonals pick their entries of it: (P, k) is entry k of diagonal P - k
+  constexpr int DGT = dg_total<NS, WV, WVI>();
+  double dg[DGT > 0 ? DGT : 1];
+  static_for<0, (DGT > 0 ? DGT : 1)>([&](auto i) { dg[decltype(i)::value] = 0.0; });
+  double yv[NS];
+  static_for<0, NS>([&](auto sc) { yv[decltype(sc)::value] = 0.0; });
+  if constexpr (WVI == E) {
+    static_for<0, 4 * RS>([&](auto i) { wl[decltype(i)::value * 64] = 0.0; });
+    for (int i = 0; i < L::WX; ++i) xst(0.0, i);
+  }
+  barrier();
+  static_for<0, NS>([&](auto pc) {
+    constexpr int P = decltype(pc)::value;
+    if constexpr (WVI == E) {
       if (P < ntot) {
         const int g = 3 * (g0 + P);
         enter(pc, std::integral_constant<int, 0>{}, std::true_type{}, P, P, io.ld(abmap[g]), io.ld(abmap[g + 1]), io.ld(abmap[g + 2]),
               T.ent_extra[P], T.ecp_ptr[P], T.ecp_ptr[P + 1], Fg[g0 + P]);
+      } else {
+        static_for<0, RS>([&](auto kc) { wl[(ROWB + decltype(kc)::value) * 64] = 0.0; });
       }
+    }
+    barrier();
+    static_for<0, P + 1>([&](auto kc) {
+      constexpr int k = decltype(kc)::value, d_ = P - k;
+      if constexpr (d_ < B) { if constexpr (diag_owner_r<WV>(d_) == WVI) dg[dg_off<NS, WV, WVI>(d_) + k] = wl[(ROWB + k) * 64]; }
     });
+    if constexpr (WVI == YU) yv[P] = wl[(ROWB + NS) * 64];
+    barrier();
+  });
+  if constexpr (WVI == E) {
     int giA[3] = {0, 0, 0}, giB[3] = {0, 0, 0};
     slots(0, giA); slots(1, giB); slots(2, giC);
     fetch(0, giA, abA); fetch(1, giB, abB);
     cur = tables(0);
+    wl[(COL + B) * 64] = corner;                         // (ROWB[0] still holds row B and y_B: the first step appends them again)
   }
-  barrier();
-  // the triangle leaves LDS: diagonal d = s - t, entries (d + j, j), j = 0 .. B - d, into the registers of its owner
-  constexpr int DGT = dg_total<NS, WV, WVI>();
-  double dg[DGT > 0 ? DGT : 1];
-  static_for<0, B>([&](auto dc) {
-    constexpr int d_ = decltype(dc)::value;
-    if constexpr (diag_owner_r<WV>(d_) == WVI) {
-      constexpr int off = dg_off<NS, WV, WVI>(d_);
-      static_for<0, B - d_ + 1>([&](auto jc) { constexpr int j = decltype(jc)::value; dg[off + j] = wl[tri(d_ + j, j) * 64]; });
-    }
-  });
-  double yv[NS];
-  static_for<0, NS>([&](auto sc) { yv[decltype(sc)::value] = 0.0; });
-  if constexpr (WVI == YU) static_for<0, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; yv[s_] = wl[(YP + s_) * 64]; });
-  double rb[RS];
-  if constexpr (WVI == E) {
-    static_for<0, NS>([&](auto kc) { constexpr int k = decltype(kc)::value; rb[k] = wl[tri(B, k) * 64]; });
-    rb[NS] = wl[(YP + B) * 64];
-  }
-  barrier();                                             // everybody has its part: the triangle's LDS becomes the exchange buffers
   static_for<0, B>([&](auto dc) {
     constexpr int d_ = decltype(dc)::value;
     if constexpr (diag_owner_r<WV>(d_) == WVI) wl[(COL + d_) * 64] = dg[dg_off<NS, WV, WVI>(d_)];
   });
   if constexpr (WVI == YU) wl[(COL + NS) * 64] = yv[0];
-  if constexpr (WVI == E) {
-    static_for<0, RS>([&](auto kc) { constexpr int k = decltype(kc)::value; wl[(ROWB + k) * 64] = rb[k]; });
-    wl[(COL + B) * 64] = rb[0];
-  }
   barrier();
   int u = 0;
   auto step = [&](auto parc, int pp) {
@@ -1255,7 +1249,7 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
   Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000), lane * 8};
   double* xs = xlds + lane;
   const PostTables T{act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off};
-  constexpr int FLAG = (NSP - 1) * NSP / 2 + 2 * (NSP + 1) + NSP;      // behind band_sweep_ldsw's window
+  constexpr int FLAG = 4 * (NSP + 1) + XL<NSP, NXM>::WX;               // behind the forward sweep's buffers
   int bad = 0;
   constexpr int NIFT = (NSF - 1) * NSF / 2;
   long long tk[6];
@@ -1348,7 +1342,7 @@ template <int NSF, int NSP, int NXM = 8>
 int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int WV = 4;
   static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
-  constexpr size_t lds_w = (size_t)((NSP - 1) * NSP / 2 + 2 * (NSP + 1) + NSP + 1) * 64 * sizeof(double);      // window | 2 x row B | y | flag
+  constexpr size_t lds_w = (size_t)(4 * (NSP + 1) + XL<NSP, NXM>::WX + 1) * 64 * sizeof(double);      // forward: column / row buffers | extras' state | flag
   constexpr size_t lds_b = (size_t)(2 * 6 * (NSP + 1) + NXM) * 64 * sizeof(double);      // backward: two buffers of six columns + WX
   constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
   static_assert(lds <= 160 * 1024, "LDS window");
