@@ -423,215 +423,17 @@ __device__ __forceinline__ void band_sweep_lds(const BandDev& p, const Io& io, d
 }
 
 // ---- backward: L^T w = y over one segment (w overwrites y), pivots in reverse -------------------------------------------------
-// ---- the same sweep by WV waves that share the 64 samples of a workgroup (fom_band_ldsw_kernel) ------------------------------------
+// ---- the post's sweep by WV waves that share the 64 samples of a workgroup (fom_band_ldsw_kernel) ----------------------------------
 // One wave cannot keep more than 15 LDS instructions in flight (lgkmcnt), which left band_sweep_lds at ~30 cycles per updated
-// entry.  The update moves an entry ALONG ITS DIAGONAL (s, t) -> (s - 1, t - 1), so the triangle is split by diagonals d = s - t:
-// wave w owns the diagonals diag_owner(d) == w (snake order: equal entry counts), reads each of its diagonals in one burst and
-// writes it back one position up -- no two waves ever touch the same entry.  Every wave reads the pivot column and derives
+// entry.  The update moves an entry ALONG ITS DIAGONAL (s, t) -> (s - 1, t - 1), so the triangle is split by diagonals d = s - t
+// (snake order: equal entry counts) and no two waves ever touch the same entry.  Every wave reads the pivot column and derives
 // 1/sqrt and the scaled column itself; the rest of a pivot is spread by role: wave ST stores the column of L and y, wave YU slides
 // the right-hand-side window, wave E (the last one) owns the extras' state, the entering node and its prefetch pipeline.
-// The entering node's row (window row B) and its right-hand side live in TWO buffers used alternately: wave E fills the buffer of
-// the next pivot while the others still read this pivot's row B, so ONE barrier per pivot is enough.
-// LDS (doubles per lane): rows 0..B-1 of the triangle | 2 x (row B: NS entries + y_B) | y_0..y_{B-1} | flag.
+// (First version, DESIGN 4a: the triangle in LDS, each wave reading its diagonals in bursts and writing them back one position
+// up, two barriers per pivot: 8.5 -> 5.2 ms per 16k samples at m = 20.  band_sweep_ldsr below keeps the diagonals in registers.)
 template <int WV> constexpr int diag_owner(int d) { const int r = d % (2 * WV); return r < WV ? r : 2 * WV - 1 - r; }
 // (register variant: the last wave -- extras, entering node -- owns no diagonal; the update is cheap there, its own chain is not)
 template <int WV> constexpr int diag_owner_r(int d) { return WV > 1 ? diag_owner<WV - 1>(d) : 0; }
-
-template <int NS, int NXM, int WV, int WVI>
-__device__ __forceinline__ void band_sweep_ldsw(const BandDev& p, const Io& io, double* __restrict__ wl, const double* __restrict__ Fg,
-                                                const int* __restrict__ abmap, const PostTables& T, int g0, int e0, int npiv, int ntot,
-                                                int L0, int& bad) {
-  constexpr int B = NS - 1, TB = B * (B + 1) / 2, RS = NS + 1, YO = TB + 2 * RS;
-  constexpr int ST = 0, YU = 1 % WV, E = WV - 1;
-  using L = XL<NS, NXM>;
-  const int offX = p.offX;
-  auto xld = [&](int idx) -> double { return io.ld(offX + idx); };
-  auto xst = [&](double v, int idx) { io.st(v, offX + idx); };
-  // window entry (a, b), a >= b, of the pivot whose row-B buffer is `par`
-  auto widx = [](int a, int b, int par) constexpr { return a < B ? tri(a, b) : TB + par * RS + b; };
-  // LDS-only barrier: nothing a wave stores to the workspace inside this sweep is read by another wave before the sweep ends
-  // (the caller's __syncthreads()), and __syncthreads() here would make every pivot wait for the column stores' acknowledgements
-  auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-
-  // node t (renamed slot u) enters at position P of the window whose row-B buffer is `par` (wave E only)
-  auto enter = [&](auto pc, auto parc, int t, int u, double ab0, double ab1, double ab2, int ex, int c0, int c1, double ft) {
-    constexpr int P = decltype(pc)::value, par = decltype(parc)::value;
-    double row[P + 1];
-    static_for<0, P>([&](auto kc) { row[decltype(kc)::value] = 0.0; });
-    double diag = 0.0, yv = 0.0;
-    static_for<0, NXM>([&](auto sc) { xst(0.0, L::X + decltype(sc)::value * NS + u); });
-    if (ex != 0) {
-      const int sl = ex - 1;
-      static_for<0, P>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        int sk = u - P + k; sk += sk < 0 ? NS : 0;
-        row[k] = xld(L::X + sl * NS + sk);
-      });
-      diag = xld(L::XD + sl); yv = xld(L::XY + sl);
-      double xo[NXM];
-      static_for<0, NXM>([&](auto oc) {
-        constexpr int o = decltype(oc)::value;
-        const int a = o > sl ? o : sl, b = o > sl ? sl : o;
-        xo[o] = (o != sl) ? xld(L::XX + a * (a - 1) / 2 + b) : 0.0;
-      });
-      static_for<0, NXM>([&](auto oc) {
-        constexpr int o = decltype(oc)::value;
-        if (o != sl) {
-          const int a = o > sl ? o : sl, b = o > sl ? sl : o;
-          xst(xo[o], L::X + o * NS + u);
-          xst(0.0, L::XX + a * (a - 1) / 2 + b);
-        }
-      });
-      for (int v = 0; v < NS; ++v) xst(0.0, L::X + sl * NS + v);
-      xst(0.0, L::XD + sl); xst(0.0, L::XY + sl);
-    }
-    if constexpr (P >= 1) row[P - 1] += ab1;
-    if constexpr (P == B) row[0] += ab2;
-    static_for<0, P>([&](auto kc) { constexpr int k = decltype(kc)::value; wl[widx(P, k, par) * 64] = row[k]; });
-    wl[widx(P, P, par) * 64] = diag + ab0;
-    if constexpr (P == B) wl[(TB + par * RS + NS) * 64] = yv + ft;
-    else wl[(YO + P) * 64] = yv + ft;
-    for (int c = c0; c < c1; ++c) {
-      const int idx = L::X + T.ecp_slot[c] * NS + u;
-      xst(xld(idx) + io.ld(T.ecp_off[c]), idx);
-    }
-  };
-
-  struct Tab { int am, lx, ex, c0, c1; double ft; };
-  auto tables = [&](int q) -> Tab {
-    Tab r{0, 0, 0, 0, 0, 0.0};
-    if (q < npiv) {
-      r.am = T.act[q]; r.lx = T.lx_ptr[q];
-      if (q + NS < ntot) { const int t = q + NS; r.ex = T.ent_extra[t]; r.c0 = T.ecp_ptr[t]; r.c1 = T.ecp_ptr[t + 1]; r.ft = Fg[g0 + t]; }
-    }
-    return r;
-  };
-  auto slots = [&](int q, int (&gi)[3]) {
-    if (q < npiv && q + NS < ntot) { const int g = 3 * (g0 + q + NS); gi[0] = abmap[g]; gi[1] = abmap[g + 1]; gi[2] = abmap[g + 2]; }
-  };
-  auto fetch = [&](int q, const int (&gi)[3], double (&ab)[3]) {
-    if (q < npiv && q + NS < ntot) { ab[0] = io.ld(gi[0]); ab[1] = io.ld(gi[1]); ab[2] = io.ld(gi[2]); }
-  };
-  double abA[3] = {0.0, 0.0, 0.0}, abB[3] = {0.0, 0.0, 0.0};
-  int giC[3] = {0, 0, 0};
-  Tab cur{0, 0, 0, 0, 0, 0.0};
-  if constexpr (WVI == E) {                              // prologue: empty window, the first NS nodes, the pipelines
-    static_for<0, YO + NS + 1>([&](auto i) { wl[decltype(i)::value * 64] = 0.0; });
-    for (int i = 0; i < L::SIZE; ++i) xst(0.0, i);
-    static_for<0, NS>([&](auto pc) {
-      constexpr int P = decltype(pc)::value;
-      if (P < ntot) {
-        const int g = 3 * (g0 + P);
-        enter(pc, std::integral_constant<int, 0>{}, P, P, io.ld(abmap[g]), io.ld(abmap[g + 1]), io.ld(abmap[g + 2]), T.ent_extra[P],
-              T.ecp_ptr[P], T.ecp_ptr[P + 1], Fg[g0 + P]);
-      }
-    });
-    int giA[3] = {0, 0, 0}, giB[3] = {0, 0, 0};
-    slots(0, giA); slots(1, giB); slots(2, giC);
-    fetch(0, giA, abA); fetch(1, giB, abB);
-    cur = tables(0);
-  }
-  barrier();
-  int u = 0;
-  auto step = [&](auto parc, int pp) {
-    constexpr int par = decltype(parc)::value;
-    Tab nxt{0, 0, 0, 0, 0, 0.0};
-    int giD[3] = {0, 0, 0};
-    const double d = wl[0];
-    if (!(d > 0.0)) bad = 1;
-    double inv = __builtin_amdgcn_rsq(d);
-    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
-    inv = inv * fma(-0.5 * d * inv, inv, 1.5);
-    double l[NS];
-    static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; l[s_] = wl[widx(s_, 0, par) * 64] * inv; });
-    const double yp = wl[YO * 64] * inv;
-    barrier();                                           // everybody has read the pivot column and y_0: the writes below may overwrite them
-    if constexpr (WVI == ST) {
-      const int base = p.offL + L0 + pp * NS;
-      static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; io.template stk<s_ - 1>(l[s_], base); });
-      io.template stk<NS - 1>(inv, base);
-      io.st(yp, p.offY + e0 + pp);
-    }
-    if constexpr (WVI == YU) {
-      double yb[NS];
-      static_for<1, NS>([&](auto sc) {
-        constexpr int s_ = decltype(sc)::value;
-        yb[s_] = s_ < B ? wl[(YO + s_) * 64] : wl[(TB + par * RS + NS) * 64];
-      });
-      static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; wl[(YO + s_ - 1) * 64] = fma(-l[s_], yp, yb[s_]); });
-    }
-    static_for<0, B>([&](auto dc) {                      // own diagonals: burst read, then write one position up
-      constexpr int dg = decltype(dc)::value;
-      if constexpr (diag_owner<WV>(dg) == WVI) {
-        double buf[B - dg];
-        static_for<dg + 1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; buf[s_ - dg - 1] = wl[widx(s_, s_ - dg, par) * 64]; });
-        static_for<dg + 1, NS>([&](auto sc) {
-          constexpr int s_ = decltype(sc)::value, t = s_ - dg;
-          wl[tri(s_ - 1, t - 1) * 64] = fma(-l[s_], l[t], buf[s_ - dg - 1]);
-        });
-      }
-    });
-    // the scalar loads of the next pivots' table entries go HERE, behind this wave's last LDS read of the pivot: they share
-    // lgkmcnt with LDS and return out of order, so the next wait for an LDS value also waits for them -- now the barrier's
-    if constexpr (WVI == E) { nxt = tables(pp + 1); slots(pp + 3, giD); }
-    if constexpr (WVI == E) {
-      // extras with a non-zero coupling to this pivot, one after the other (requesting the rows of four of them together was not
-      // faster here either: 5.36 vs 5.24 ms)
-      const int am = cur.am;
-      if (am != 0) {
-        double le[NXM];
-        int k = p.offLx + cur.lx;
-        static_for<0, NXM>([&](auto sc) {
-          constexpr int sl = decltype(sc)::value;
-          le[sl] = 0.0;
-          if (am & (1 << sl)) {
-            double xv[NS];
-            static_for<0, NS>([&](auto tc) {
-              constexpr int t = decltype(tc)::value;
-              int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
-              xv[t] = xld(L::X + sl * NS + st_);
-            });
-            const double xy = xld(L::XY + sl), xd = xld(L::XD + sl);
-            const double v = xv[0] * inv;
-            le[sl] = v;
-            io.st(v, k); ++k;
-            xst(fma(-v, yp, xy), L::XY + sl);
-            xst(fma(-v, v, xd), L::XD + sl);
-            static_for<1, NS>([&](auto tc) {
-              constexpr int t = decltype(tc)::value;
-              int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
-              xst(fma(-v, l[t], xv[t]), L::X + sl * NS + st_);
-            });
-          }
-        });
-        double xx[NXM * (NXM - 1) / 2];
-        static_for<0, NXM*(NXM - 1) / 2>([&](auto ic) { xx[decltype(ic)::value] = xld(L::XX + decltype(ic)::value); });
-        static_for<1, NXM>([&](auto ac) {
-          constexpr int a = decltype(ac)::value;
-          static_for<0, a>([&](auto bc) {
-            constexpr int b = decltype(bc)::value;
-            constexpr int i = a * (a - 1) / 2 + b;
-            xst(fma(-le[a], le[b], xx[i]), L::XX + i);
-          });
-        });
-      }
-      if (pp + NS < ntot) enter(std::integral_constant<int, B>{}, std::integral_constant<int, 1 - par>{}, pp + NS, u, abA[0], abA[1], abA[2],
-                                cur.ex, cur.c0, cur.c1, cur.ft);
-      else static_for<0, RS>([&](auto kc) { wl[(TB + (1 - par) * RS + decltype(kc)::value) * 64] = 0.0; });
-      abA[0] = abB[0]; abA[1] = abB[1]; abA[2] = abB[2];
-      fetch(pp + 2, giC, abB);
-      giC[0] = giD[0]; giC[1] = giD[1]; giC[2] = giD[2];
-      cur = nxt;
-    }
-    u = u + 1 == NS ? 0 : u + 1;
-    barrier();
-  };
-#pragma unroll 1
-  for (int pp = 0; pp < npiv; pp += 2) {
-    step(std::integral_constant<int, 0>{}, pp);
-    if (pp + 1 < npiv) step(std::integral_constant<int, 1>{}, pp + 1);
-  }
-}
 
 // (registers) offsets of a wave's diagonals in its flat register array: diagonal d has B - d + 1 entries (t = 0 .. B - d)
 template <int NS, int WV, int WVI> constexpr int dg_off(int d) {
@@ -1230,7 +1032,7 @@ __device__ __forceinline__ void band_bsweep_ldsw(const BandDev& p, const Io& io,
   }
 }
 
-// WV waves per 64 samples: the eight fins are independent (shared over the waves), the post's forward sweep is band_sweep_ldsw,
+// WV waves per 64 samples: the eight fins are independent (shared over the waves), the post's forward sweep is band_sweep_ldsr,
 // its backward sweep runs on wave 0 with a deeper column ring
 template <int NSF, int NSP, int NXM, int WV>
 __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* __restrict__ abmap, const double* __restrict__ Fg,
