@@ -95,6 +95,9 @@ SIGNATURES = {
     "finrom_fom_set_small": (C.c_int, [C.c_void_p, C.POINTER(FomSmallDesc)]),
     "finrom_fom_set_gradient": (C.c_int, [C.c_void_p, C.POINTER(FomGradDesc)]),
     "finrom_fom_set_band": (C.c_int, [C.c_void_p, C.POINTER(FomBandDesc)]),
+    "finrom_fom_band_validate": (C.c_int, [C.POINTER(FomBandDesc), C.c_int32, C.c_int32, C.c_int32]),
+    "finrom_fom_last_path": (C.c_int, [C.c_void_p]),
+    "finrom_fom_set_small_max": (C.c_int, [C.c_void_p, C.c_int32]),
     "finrom_fom_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 5),
     "finrom_rom_create": (C.c_int, [C.POINTER(RomDesc), C.POINTER(C.c_void_p)]),
     "finrom_rom_destroy": (None, [C.c_void_p]),
@@ -116,6 +119,11 @@ SIGNATURES = {
     "finrom_solve_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 8),
     "finrom_sub": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
 }
+
+ABI_VERSION = 9
+# finrom_fom_last_path codes (include/finrom.h)
+FOM_PATHS = {0: "none", 1: "small_lds", 2: "small_global", 3: "interpreter", 4: "band_registers", 5: "band_lds_4wave",
+             6: "band_lds_1wave"}
 
 _lib = None
 
@@ -139,7 +147,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.finrom_version() != 8:
+        if L.finrom_version() != ABI_VERSION:
             raise FinromError("libfinrom_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -28,7 +28,8 @@ void Scratch::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 
 // ---- profiling -------------------------------------------------------------------------
 static const char* kSlotNames[K_NUM] = {"pack", "fom_assemble", "fom_chol_solve", "unpack_w", "rom_proj_mfma",
-                                        "rom_reduced_solve", "subfin_avg", "sampler_gemm_exp", "misc"};
+                                        "rom_reduced_solve", "subfin_avg", "sampler_gemm_exp", "misc",
+                                        "fom_path_small", "fom_path_interpreter", "fom_path_band_registers", "fom_path_band_lds_4wave"};
 struct Pending { int slot; hipEvent_t e0, e1; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
@@ -61,6 +62,7 @@ static void drain_pending() {
     float ms = 0.f;
     if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       g_ms[p.slot] += ms; g_cnt[p.slot] += 1;
+      if (p.slot >= K_FOM_PATH_SMALL && p.slot <= K_FOM_PATH_BAND_LDSW) { g_ms[K_FOM] += ms; g_cnt[K_FOM] += 1; }
     }
     g_pool.push_back(p.e0); g_pool.push_back(p.e1);
   }
@@ -83,6 +85,7 @@ struct finrom_fom_s {
   FomDev band_asm{};                   // parameters of the band sweep's assembly pre-pass (fom_assemble_kernel)
   std::vector<void*> owned;
   Scratch xT, Gw, gradT, qtmp;
+  int last_path = FINROM_FOM_PATH_NONE;   // finrom_fom_last_path
 };
 struct finrom_rom_s {
   RomDev d{};
@@ -326,11 +329,13 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
     if (!(stages & 2)) return 0;
     int rc;
     if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;
+    h->last_path = h->small.in_lds ? FINROM_FOM_PATH_SMALL_LDS : FINROM_FOM_PATH_SMALL_GLOBAL;
     return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, qoi, w, info, st);
   }
   static const bool env_no_band = getenv("FINROM_NO_BAND") != nullptr;
   if (h->band.on && !env_no_band) {
     const BandDev& b = h->band;
+    h->last_path = band_path(b);
     const int64_t limit = fom_chunk_samples(d, &b);
     const int64_t npieces = (S + limit - 1) / limit;
     const int64_t chunk = npieces <= 1 ? limit : ((S + npieces - 1) / npieces + 63) / 64 * 64;
@@ -350,6 +355,7 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
     }
     return 0;
   }
+  h->last_path = FINROM_FOM_PATH_INTERPRETER;
   // equal pieces when the batch exceeds the workspace bound (a short last piece would leave the GPU mostly idle)
   const int64_t limit = fom_chunk_samples(d), npieces = (S + limit - 1) / limit;
   const int64_t chunk = npieces <= 1 ? limit : ((S + npieces - 1) / npieces + 63) / 64 * 64;
@@ -374,6 +380,18 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
 int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, void* stream) {
   if (!h || S < 0 || (S > 0 && (!x || (!qoi && h->d.n_obs > 0)))) { set_error("fom_solve: bad argument"); return FINROM_ERR_ARG; }
   return fom_solve_stages(h, x, S, qoi, w, info, (hipStream_t)stream, 3);
+}
+
+int finrom_fom_last_path(finrom_fom_t h) {
+  if (!h) { set_error("fom_last_path: null handle"); return FINROM_ERR_ARG; }
+  return h->last_path;
+}
+
+int finrom_fom_set_small_max(finrom_fom_t h, int32_t small_max) {
+  if (!h || small_max < 0) { set_error("fom_set_small_max: bad argument"); return FINROM_ERR_ARG; }
+  if (small_max > 0 && h->small.rec == nullptr) { set_error("fom_set_small_max: finrom_fom_set_small has not been called"); return FINROM_ERR_ARG; }
+  h->small.small_max = small_max;
+  return 0;
 }
 
 int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* a) {
@@ -469,15 +487,25 @@ int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* a) {
   return 0;
 }
 
-int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
-  if (!h || !a) { set_error("fom_set_band: null argument"); return FINROM_ERR_ARG; }
-  const FomDev& d = h->d;
+// Host-only check of a band descriptor against the sizes of the FOM it belongs to (every index the kernels dereference, the
+// privacy of the slots the fins write to, the window / pipeline preconditions).  No device call: also exported as
+// finrom_fom_band_validate so that a descriptor can be checked on a box without a GPU (tools/asan_validators.py).
+static int validate_band(const finrom_fom_band_desc* a, int n, int xdim, int n_obs, int64_t* gsize_out, int64_t* nL_out) {
+  if (!a || n <= 0 || xdim <= 0 || n_obs < 0) { set_error("fom_set_band: null argument"); return FINROM_ERR_ARG; }
+  struct { int n, xdim, n_obs; } d{n, xdim, n_obs};
   auto bad = [&](const char* what) { set_error(std::string("fom_set_band: invalid ") + what); return FINROM_ERR_ARG; };
   if (!band_supported(a->NSF, a->NSP, a->NX)) { set_error("fom_set_band: window sizes not built into the library"); return FINROM_ERR_UNSUPPORTED; }
   if (a->nfins < 0 || a->npf < 0 || a->nif != a->NSF - 1 || a->npost <= 0 || a->nAB <= 0 || a->nterms < 0 || a->nLx < 0) return bad("sizes");
-  const int n = d.n, G = a->nfins * (a->npf + a->nif) + a->npost;
+  // the sweeps' prologue fills a whole window of NS nodes and their software pipelines request the entering node NS positions
+  // ahead of the pivot: a segment with fewer pivots than window slots is not a shape the kernels were written for
+  if (a->nfins > 0 && a->npf < a->NSF) return bad("npf (a fin needs at least NSF pivots)");
+  if (a->npost < a->NSP) return bad("npost (the post needs at least NSP pivots)");
+  const int G = a->nfins * (a->npf + a->nif) + a->npost;
   if ((int64_t)a->nfins * a->npf + a->npost != n) return bad("pivot count (must equal the number of dofs)");
-  if (a->nAB <= 0 || !a->abmap) return bad("nAB / abmap");
+  // every table is dereferenced below and by the kernels: a missing pointer is a descriptor error, not a host fault
+  if (!a->abmap || !a->ab_c0 || !a->ab_ptr || !a->Fg || !a->act || !a->lx_ptr || !a->ent_extra || !a->ecp_ptr || !a->perm ||
+      (a->nterms > 0 && (!a->ab_idx || !a->ab_w)) || (a->nfins > 0 && (!a->schur_off || !a->iface_elim)) ||
+      (d.n_obs > 0 && !a->obs_ptr)) return bad("table pointer (null)");
   for (int e = 0; e < 3 * G; ++e) if (a->abmap[e] < 0 || a->abmap[e] >= a->nAB) return bad("abmap");
   const int64_t nL = (int64_t)a->nfins * a->npf * a->NSF + (int64_t)a->npost * a->NSP;
   const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n + BAND_LDS_XSIZE;
@@ -492,11 +520,31 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
     if (a->ent_extra[p] < 0 || a->ent_extra[p] > a->NX) return bad("ent_extra");
     if (a->ecp_ptr[p + 1] < a->ecp_ptr[p]) return bad("ecp_ptr");
   }
-  for (int c = 0; c < a->ecp_ptr[a->npost]; ++c)
+  const int necp_ = a->ecp_ptr[a->npost];
+  if (necp_ > 0 && (!a->ecp_slot || !a->ecp_off)) return bad("table pointer (null)");
+  for (int c = 0; c < necp_; ++c)
     if (a->ecp_slot[c] < 0 || a->ecp_slot[c] >= a->NX || a->ecp_off[c] < 0 || a->ecp_off[c] >= a->nAB) return bad("ecp_slot / ecp_off");
   const int nift = a->nif * (a->nif + 1) / 2;
   for (int t = 0; t < a->nfins * nift; ++t) if (a->schur_off[t] < 0 || a->schur_off[t] >= a->nAB) return bad("schur_off");
-  for (int t = 0; t < a->nfins * a->nif; ++t) if (a->iface_elim[t] < 0 || a->iface_elim[t] >= n) return bad("iface_elim");
+  // (interface nodes are POST nodes: the fins' backward sweeps read their w after the post's has written it)
+  for (int t = 0; t < a->nfins * a->nif; ++t) if (a->iface_elim[t] < a->nfins * a->npf || a->iface_elim[t] >= n) return bad("iface_elim");
+  {
+    // The fins of a workgroup are swept by DIFFERENT waves (fom_band_ldsw_kernel), each adding its Schur complement to the post's
+    // value slots with a plain load-add-store: a slot written by two fins would race.  Slots are private per fin, distinct
+    // within a fin, and not shared with plain (read-only, de-duplicated) value slots of segment nodes other than the post's
+    // own interface entries -- i.e. a Schur / extra-coupling slot appears in abmap at most once.
+    std::vector<int> owner(a->nAB, -1);                 // fin that writes the slot
+    for (int f = 0; f < a->nfins; ++f)
+      for (int t = 0; t < nift; ++t) {
+        const int off = a->schur_off[f * nift + t];
+        if (owner[off] >= 0) return bad(owner[off] == f ? "schur_off (slot repeated within a fin)" : "schur_off (slot shared by two fins)");
+        owner[off] = f;
+      }
+    std::vector<int> uses(a->nAB, 0);
+    for (int e = 0; e < 3 * G; ++e) if (a->abmap[e] >= 0 && a->abmap[e] < a->nAB) ++uses[a->abmap[e]];
+    for (int c = 0; c < necp_; ++c) ++uses[a->ecp_off[c]];
+    for (int e = 0; e < a->nAB; ++e) if (owner[e] >= 0 && uses[e] > 1) return bad("schur_off (a slot the fins write to is read by more than one entry)");
+  }
   {
     std::vector<char> seen(n, 0);
     for (int i = 0; i < n; ++i) { int v = a->perm[i]; if (v < 0 || v >= n || seen[v]) return bad("perm"); seen[v] = 1; }
@@ -504,8 +552,24 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (d.n_obs > 0) {
     if (a->obs_ptr[0] != 0) return bad("obs_ptr");
     for (int o = 0; o < d.n_obs; ++o) if (a->obs_ptr[o + 1] < a->obs_ptr[o]) return bad("obs_ptr");
+    if (a->obs_ptr[d.n_obs] > 0 && (!a->obs_idx || !a->obs_w)) return bad("table pointer (null)");
     for (int t = 0; t < a->obs_ptr[d.n_obs]; ++t) if (a->obs_idx[t] < 0 || a->obs_idx[t] >= n) return bad("obs_idx");
   }
+  if (gsize_out) *gsize_out = gsize;
+  if (nL_out) *nL_out = nL;
+  return 0;
+}
+
+int finrom_fom_band_validate(const finrom_fom_band_desc* a, int32_t n, int32_t xdim, int32_t n_obs) {
+  return validate_band(a, n, xdim, n_obs, nullptr, nullptr);
+}
+
+int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
+  if (!h || !a) { set_error("fom_set_band: null argument"); return FINROM_ERR_ARG; }
+  const FomDev& d = h->d;
+  int64_t gsize = 0, nL = 0;
+  if (int rc = validate_band(a, d.n, d.xdim, d.n_obs, &gsize, &nL)) return rc;
+  const int n = d.n, G = a->nfins * (a->npf + a->nif) + a->npost, nift = a->nif * (a->nif + 1) / 2;
   BandDev b{};
   b.n = n; b.n_obs = d.n_obs; b.xdim = d.xdim; b.gsize = (int)gsize; b.nAB = a->nAB; b.nL = (int)nL; b.nLx = a->nLx;
   b.NSF = a->NSF; b.NSP = a->NSP; b.NX = a->NX; b.nfins = a->nfins; b.npf = a->npf; b.nif = a->nif; b.npost = a->npost;
@@ -608,8 +672,10 @@ int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int
     if (!q) { if ((rc = h->qtmp.reserve((size_t)S * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
     FomSmallGrad g;
     g.data = data; g.data_stride = data_per_sample ? d.n_obs : 0; g.grad = grad; g.J = J;
+    h->last_path = h->small.in_lds ? FINROM_FOM_PATH_SMALL_LDS : FINROM_FOM_PATH_SMALL_GLOBAL;
     return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, q, nullptr, info, st, g);
   }
+  h->last_path = FINROM_FOM_PATH_INTERPRETER;
   const size_t per_sample = ((size_t)d.gsize + 2 * d.xdim) * sizeof(double);
   int64_t chunk = (int64_t)((size_t)48 << 30) / (int64_t)per_sample;
   chunk = std::max<int64_t>(64, chunk / 64 * 64);
@@ -642,6 +708,15 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   if (a->row_ptr[0] != 0 || a->row_ptr[a->n] != a->nterms) { set_error("rom_create: invalid row_ptr"); return FINROM_ERR_ARG; }
   for (int i = 0; i < a->n; ++i) if (a->row_ptr[i + 1] < a->row_ptr[i]) { set_error("rom_create: invalid row_ptr"); return FINROM_ERR_ARG; }
   for (int t = 0; t < a->nterms; ++t) if (a->term_p[t] < 0 || a->term_p[t] > a->P) { set_error("rom_create: invalid term_p"); return FINROM_ERR_ARG; }
+  // a row lists each theta index at most once: the pattern-uniform k-step tables below fill a slot with the SUM of the row's
+  // terms that carry the slot's index, so a repeated index would be counted once per repetition
+  for (int i = 0; i < a->n; ++i) {
+    unsigned seen = 0;
+    for (int t = a->row_ptr[i]; t < a->row_ptr[i + 1]; ++t) {
+      if (seen & (1u << a->term_p[t])) { set_error("rom_create: a row of psi lists the same theta index twice (merge the terms)"); return FINROM_ERR_ARG; }
+      seen |= 1u << a->term_p[t];
+    }
+  }
   const int r = a->r, NB = (r + 15) / 16, rp = 16 * NB;
   if (NB > 13) { set_error("rom_create: basis size > 208 not supported"); return FINROM_ERR_UNSUPPORTED; }
 
@@ -1009,7 +1084,7 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
       if ((rc = h->vw.reserve(vw_bytes + gp_bytes))) return rc;
       if (!h->grad_ticket.p) {                          // arrival counters: zero once, the kernel leaves them zero
         if ((rc = h->grad_ticket.reserve(ROM_SPLITK_MAX_S * sizeof(int)))) return rc;
-        FR_HIP(hipMemsetAsync(h->grad_ticket.p, 0, ROM_SPLITK_MAX_S * sizeof(int), st));
+        FR_HIP(hipMemset(h->grad_ticket.p, 0, ROM_SPLITK_MAX_S * sizeof(int)));      // synchronous: ordered before ANY stream's first use
       }
       ga.vw = (double*)h->vw.p; ga.gpart = (double*)((char*)h->vw.p + vw_bytes); ga.ticket = (int*)h->grad_ticket.p;
       {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "finrom.h"
@@ -31,6 +32,11 @@ enum KernelSlot {
   K_AVG,           // theta = S k
   K_SAMPLER,       // k = exp(0.5 U^T xi)
   K_MISC,
+  // one slot per FOM schedule (finrom_fom_last_path); a launch timed here is ALSO added to K_FOM, the aggregate bench.py reads
+  K_FOM_PATH_SMALL,
+  K_FOM_PATH_INTERP,
+  K_FOM_PATH_BAND_REG,
+  K_FOM_PATH_BAND_LDSW,
   K_NUM
 };
 struct ScopedKernelTimer {
@@ -48,6 +54,21 @@ int upload(T** dptr, const T* host, size_t count) {
   FR_HIP(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
   return 0;
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's function object: once per device, and
+// safe when two host threads launch on different handles (a lost race only repeats the idempotent call)
+struct PerDeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  template <class F> int run(F&& f) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return f();
+    const unsigned long long bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    const int rc = f();
+    if (rc == 0) done.fetch_or(bit, std::memory_order_release);
+    return rc;
+  }
+};
 
 // grow-only device scratch buffer owned by a handle
 struct Scratch {
@@ -142,6 +163,7 @@ struct BandDev {
 constexpr int BAND_LDS_XSIZE = 256;
 bool band_supported(int NSF, int NSP, int NX);
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st);
+int band_path(const BandDev& p);      // FINROM_FOM_PATH_* of the kernel launch_fom_band picks for these window sizes
 
 // ---- learned error model (mlp_kernels.hip, finrom_mlp_*) ----------------------------------
 struct MlpDev {

@@ -1148,11 +1148,10 @@ int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* q
   constexpr size_t lds_b = (size_t)(2 * 6 * (NSP + 1) + NXM) * 64 * sizeof(double);      // backward: two buffers of six columns + WX
   constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
   static_assert(lds <= 160 * 1024, "LDS window");
-  static bool once = false;
-  if (!once) {
-    FR_HIP(hipFuncSetAttribute((const void*)fom_band_ldsw_kernel<NSF, NSP, NXM, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  if (int rc = once.run([&]() -> int {
+        FR_HIP(hipFuncSetAttribute((const void*)fom_band_ldsw_kernel<NSF, NSP, NXM, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        return 0; })) return rc;
   hipLaunchKernelGGL((fom_band_ldsw_kernel<NSF, NSP, NXM, WV>), dim3((unsigned)nblk), dim3(64 * WV), lds, st, p, p.abmap, p.Fg, p.act,
                      p.lx_ptr, p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx,
                      p.obs_w, Gw, S, qoi, info);
@@ -1168,11 +1167,10 @@ int launch_lds(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qo
   constexpr size_t lds_b = (size_t)(XL<NSP, NXM>::WX + NXM) * 64 * sizeof(double);               // backward: XL::WX at its usual index
   constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
   static_assert(lds <= 160 * 1024, "LDS window");
-  static bool once = false;
-  if (!once) {
-    FR_HIP(hipFuncSetAttribute((const void*)fom_band_lds_kernel<NSF, NSP, NXM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    once = true;
-  }
+  static PerDeviceOnce once;
+  if (int rc = once.run([&]() -> int {
+        FR_HIP(hipFuncSetAttribute((const void*)fom_band_lds_kernel<NSF, NSP, NXM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        return 0; })) return rc;
   hipLaunchKernelGGL((fom_band_lds_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.abmap, p.Fg, p.act, p.lx_ptr,
                      p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx, p.obs_w,
                      Gw, S, qoi, info);
@@ -1198,14 +1196,28 @@ bool band_supported(int NSF, int NSP, int NX) {
   return NX <= 8 && ((NSF == 6 && NSP == 18) || (NSF == 7 && NSP == 22));                                           // window in LDS
 }
 
+static bool band_one_wave_lds() {
+#ifdef FINROM_BUILD_ONE_WAVE_LDS
+  static const bool one_wave = getenv("FINROM_BAND_LDS_ONE_WAVE") != nullptr;
+  return one_wave;
+#else
+  return false;
+#endif
+}
+
+int band_path(const BandDev& p) {
+  if (p.NSP <= 14) return FINROM_FOM_PATH_BAND_REGISTERS;
+  return band_one_wave_lds() ? FINROM_FOM_PATH_BAND_LDS_1WAVE : FINROM_FOM_PATH_BAND_LDS_4WAVE;
+}
+
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   if (nblk == 0) return 0;
-  ScopedKernelTimer t(K_FOM, st);
+  ScopedKernelTimer t(p.NSP <= 14 ? K_FOM_PATH_BAND_REG : K_FOM_PATH_BAND_LDSW, st);
   if (p.NSF == 3 && p.NSP == 6) return launch_t<3, 6>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 4 && p.NSP == 10) return launch_t<4, 10>(p, Gw, nblk, S, qoi, info, st);
   if (p.NSF == 5 && p.NSP == 14) return launch_t<5, 14>(p, Gw, nblk, S, qoi, info, st);
 #ifdef FINROM_BUILD_ONE_WAVE_LDS      // A/B: the single-wave LDS sweep (a minute of compile time; -DFINROM_BUILD_ONE_WAVE_LDS + FINROM_BAND_LDS_ONE_WAVE=1)
-  static const bool one_wave = getenv("FINROM_BAND_LDS_ONE_WAVE") != nullptr;
+  const bool one_wave = band_one_wave_lds();
   if (one_wave && p.NSF == 6 && p.NSP == 18) return launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st);
   if (one_wave && p.NSF == 7 && p.NSP == 22) return launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st);
 #endif

@@ -334,7 +334,7 @@ int launch_fom_assemble(const FomDev& p, const double* xT, int64_t nblk, double*
 
 int launch_fom(const FomDev& p, const double* xT, int64_t nblk, int64_t S, double* Gw, double* qoi, int* info, hipStream_t st) {
   if (nblk == 0) return 0;
-  ScopedKernelTimer t(K_FOM, st);
+  ScopedKernelTimer t(K_FOM_PATH_INTERP, st);
   const size_t lds = (size_t)(p.cache_slots + 5 + (p.fused ? p.xdim : 0)) * 64 * sizeof(double);
   if (p.fwd_chunk == 16)
     hipLaunchKernelGGL(fom_vm_kernel<16>, dim3((unsigned)nblk), dim3(64), lds, st, p, p.f_a, p.f_kb, p.f_d, p.f_mask, p.rhs, p.f_imm, xT,
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64) void fom_adjoint_kernel(FomDev p, const int* __
 int launch_fom_adjoint(const FomDev& p, int64_t nblk, int64_t S, double* Gw, const double* qoi, const double* data,
                        int64_t data_stride, double* gradT, double* J, hipStream_t st) {
   if (nblk == 0) return 0;
-  ScopedKernelTimer t(K_FOM, st);
+  ScopedKernelTimer t(K_FOM_PATH_INTERP, st);
   const size_t lds = (size_t)(p.n_obs > 0 ? p.n_obs : 1) * 64 * sizeof(double);
   hipLaunchKernelGGL(fom_adjoint_kernel, dim3((unsigned)nblk), dim3(64), lds, st, p, p.r_a, p.r_kb, p.r_d, p.bt_ptr, p.bt_obs,
                      p.bt_w, p.g_ptr, p.g_a, p.g_b, p.g_w, Gw, S, qoi, data, data_stride, gradT, J);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void fom_small_kernel(FomDev p, FomSmallDev q,
 int launch_fom_small(const FomDev& p, const FomSmallDev& q, const double* x, int64_t S, double* Gscratch, double* qoi, double* w,
                      int* info, hipStream_t st, const FomSmallGrad& g) {
   if (S == 0) return 0;
-  ScopedKernelTimer t(K_FOM, st);
+  ScopedKernelTimer t(K_FOM_PATH_SMALL, st);
   if (q.in_lds) {
     const size_t lds = (size_t)(p.gsize + p.xdim) * sizeof(double);
     FR_HIP(hipFuncSetAttribute((const void*)fom_small_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -28,8 +28,8 @@ template <int NB>
 static int launch_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                          hipStream_t st, double* w_r, double* qoi_r, const RomGradArgs& ga) {
   constexpr int lds = 3 * (NB * (NB + 1) / 2) * 256 * (int)sizeof(double);
-  static bool once = false;
-  if (!once) { FR_HIP(hipFuncSetAttribute((const void*)rom_proj_splitk_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); once = true; }
+  static PerDeviceOnce once;
+  if (int rc = once.run([&]() -> int { FR_HIP(hipFuncSetAttribute((const void*)rom_proj_splitk_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); return 0; })) return rc;
   hipLaunchKernelGGL(rom_proj_splitk_kernel<NB>, dim3((unsigned)S), dim3(256), lds, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta, ga);
   FR_HIP(hipGetLastError());
   return 0;

@@ -12,12 +12,13 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, min(total, lo + per)
 
 
-def gather_rows(local, world: int, total: int | None = None):
+def gather_rows(local, world: int, total: int | None = None, force: bool = False):
     """All ranks contribute ``local`` [rows_r, d] (torch tensor; every rank but the last must hold
-    ceil(total/world) rows); returns the concatenation [total, d] on every rank."""
+    ceil(total/world) rows); returns the concatenation [total, d] on every rank.  ``force``: run the
+    collective even in a one-rank group (the RCCL rehearsal of bench.py --force-pg)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local
     per = local.shape[0]
     if total is not None:

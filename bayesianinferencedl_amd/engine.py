@@ -157,12 +157,9 @@ class FomEngine:
         if USE_BAND and ops is not None:
             self._enable_band(ops, c0_csr, W_csr, rhs, B_obs)
 
-    def _enable_band(self, ops, c0_csr, W_csr, rhs, B_obs):
-        """Install the frontal band sweep (finrom_fom_set_band) when the mesh has a band plan and the library was built with
-        its window sizes; otherwise the handle keeps the interpreter."""
-        bp = ops.band_plan()
-        if bp is None:
-            return
+    @staticmethod
+    def band_descriptor(bp, xdim, c0_csr, W_csr, rhs, B_obs):
+        """finrom_fom_band_desc of band plan `bp` for one operator table -> (descriptor, arrays it borrows, physical slots)."""
         c0, ptr, idx, w = bp.ab_table(c0_csr, W_csr)
         abmap, c0p, ptrp, idxp, wp = bp.compact_slots(c0, ptr, idx, w)      # logical -> physical value slots (duplicates shared)
         F = np.asarray(rhs, dtype=np.float64)
@@ -186,12 +183,21 @@ class FomEngine:
                         ecp_ptr=I(bp.ecp_ptr), ecp_slot=I(bp.ecp_slot), ecp_off=I(abmap[bp.ecp_off] if len(bp.ecp_off) else bp.ecp_off),
                         schur_off=I(schur), iface_elim=I(bp.iface_elim), perm=I(bp.perm),
                         obs_ptr=I(optr), obs_idx=I(oidx), obs_w=D(ow))
+        return d, keep, len(c0p)
+
+    def _enable_band(self, ops, c0_csr, W_csr, rhs, B_obs):
+        """Install the frontal band sweep (finrom_fom_set_band) when the mesh has a band plan and the library was built with
+        its window sizes; otherwise the handle keeps the interpreter."""
+        bp = ops.band_plan()
+        if bp is None:
+            return
+        d, keep, nslots = self.band_descriptor(bp, self.xdim, c0_csr, W_csr, rhs, B_obs)
         rc = lib().finrom_fom_set_band(self._h, C.byref(d))
         if rc == -4:                                     # FINROM_ERR_UNSUPPORTED: window sizes not built in -> interpreter
             return
         check(rc, "finrom_fom_set_band")
         self.band = bp
-        self.band_slots = len(c0p)          # physical value slots per sample (bench: algorithmic bytes)
+        self.band_slots = nslots            # physical value slots per sample (bench: algorithmic bytes)
 
     def solve(self, X, want_w=False):
         b = _Batch(X, self.xdim)
@@ -202,6 +208,18 @@ class FomEngine:
         check(lib().finrom_fom_solve(self._h, b.ptr, S, qp, wp, ip, b.stream), "finrom_fom_solve")
         return {"qoi": b.out(qoi, (S, self.n_obs)), "w": b.out(w, (S, self.n)) if want_w else None,
                 "info": b.out(info, (S,), "i4")}
+
+    def last_path(self):
+        """Name of the schedule the most recent solve / gradient on this handle launched (finrom_fom_last_path):
+        'small_lds', 'small_global', 'interpreter', 'band_registers', 'band_lds_4wave' ('none' before the first call)."""
+        rc = lib().finrom_fom_last_path(self._h)
+        if rc < 0:
+            check(rc, "finrom_fom_last_path")
+        return _ffi.FOM_PATHS[rc]
+
+    def set_small_max(self, small_max):
+        """Move the batch-size threshold of the small-batch schedule (0: every batch takes the throughput path)."""
+        check(lib().finrom_fom_set_small_max(self._h, int(small_max)), "finrom_fom_set_small_max")
 
     def _enable_gradient(self):
         """One-time tables of the adjoint gradient (finrom_fom_set_gradient)."""

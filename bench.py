@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 run: nccl (= RCCL over xGMI, one rank per GPU) or gloo (host "
                          "gather; ranks may then share a GPU: rehearsal of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="create the torch.distributed process group and run the per-step gather even with ONE rank (the "
+                         "collective then really executes: RCCL communicator init + all_gather_into_tensor on device tensors at "
+                         "world = 1) -- rehearsal of the N > 1 code path on a one-GPU box")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / sharding rehearsal without a GPU: ranks start, build their shard of the globally keyed "
                          "inputs, gather a stand-in over gloo and rank 0 prints the JSON line with value = null")
@@ -196,8 +200,15 @@ def main():
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    use_pg = world > 1 or args.force_pg                   # process group + per-step gather (always for N > 1)
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:               # plain `python bench.py --force-pg`: a one-rank rendezvous of our own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -234,13 +245,13 @@ def main():
 
     def step():
         res = pairs.solve_pairs(X)
-        if world > 1:   # the one exchange step: QoI pairs of every shard (RCCL all_gather over xGMI)
+        if use_pg:      # the one exchange step: QoI pairs of every shard (RCCL all_gather over xGMI)
             loc = torch.cat([res["qoi"], res["qoi_r"]], dim=1)
-            res["gathered"] = gather_rows(loc if args.backend == "nccl" else loc.cpu(), world)
+            res["gathered"] = gather_rows(loc if args.backend == "nccl" else loc.cpu(), world, force=True)
         return res
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -270,6 +281,7 @@ def main():
         del Xh
     L.finrom_profile_reset()
     L.finrom_profile_enable(0 if args.no_profile else 1)
+    fence()                                               # barrier + device synchronisation on both sides of the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -281,12 +293,12 @@ def main():
 
     cdev = dev if args.backend == "nccl" else torch.device("cpu")        # where the collectives' tensors live
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     # checksum of the gathered QoI pairs in GLOBAL sample order (not timed): equal for every GPU count on the same total
     import hashlib
-    full = res["gathered"] if world > 1 else torch.cat([res["qoi"], res["qoi_r"]], dim=1)
+    full = res["gathered"] if use_pg else torch.cat([res["qoi"], res["qoi_r"]], dim=1)
     gathered_sha = hashlib.sha256(full.cpu().numpy().tobytes()).hexdigest() if rank == 0 else None
     del full
 
@@ -304,7 +316,7 @@ def main():
         dto = time.perf_counter() - t0
         L.finrom_profile_enable(0)
         tmax = torch.tensor([dto], dtype=torch.float64, device=cdev)
-        if world > 1:
+        if use_pg:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dto = float(tmax.item())
         dq = float((torch.linalg.norm(res_o["qoi_r"] - res["qoi_r"], dim=1) / torch.linalg.norm(res["qoi_r"], dim=1)).max().item())
@@ -350,14 +362,15 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
             "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0},
-            "gathered_sha256": gathered_sha, "backend": args.backend if world > 1 else None,
+            "gathered_sha256": gathered_sha, "backend": args.backend if use_pg else None,
+            "process_group": {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced": bool(args.force_pg and world == 1)} if use_pg else None,
             "kernels_serial_ms": serial_ms,
             "host_io_pairs_per_s": host_io,
             "cpu_baseline_all_cores": cpu_all,
             "other_projection": other,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 8
+#define FINROM_ABI_VERSION 9
 
 typedef enum {
   FINROM_OK = 0,
@@ -212,6 +212,28 @@ typedef struct {
   const int32_t* obs_ptr; const int32_t* obs_idx; const double* obs_w;      /* B_obs (CSR) over elimination indices */
 } finrom_fom_band_desc;
 int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* desc);
+/* The checks finrom_fom_set_band applies before it touches the device, for a FOM of n dofs, xdim parameters and n_obs
+ * observation rows: every index the kernels dereference, no missing table, npf >= NSF and npost >= NSP, and the slots the
+ * fins write their Schur complements to (schur_off) private -- not shared between fins, not repeated, read by one entry
+ * only (the four-wave kernel sweeps the fins of a sample block on different waves).  Host only: usable without a GPU. */
+int finrom_fom_band_validate(const finrom_fom_band_desc* desc, int32_t n, int32_t xdim, int32_t n_obs);
+
+/* ---- which schedule ran (Fin.forward has ONE solver, fom/forward_solve.py:286; this library has several schedules of the
+ * same factorisation, picked by batch size and mesh) ------------------------------------------------------------------- *
+ * finrom_fom_last_path: the schedule the most recent finrom_fom_solve / finrom_fom_gradient / finrom_solve_pairs call on
+ * this handle launched (FINROM_FOM_PATH_NONE before the first call).  Tests assert on it so that a dispatch change cannot
+ * silently route a case away from the kernel it was written for; each path also has its own finrom_profile_* slot.
+ * finrom_fom_set_small_max moves the batch-size threshold of the small-batch schedule on an existing handle (0 = never;
+ * negative = error); it does not install a schedule that finrom_fom_set_small has not installed. */
+#define FINROM_FOM_PATH_NONE 0
+#define FINROM_FOM_PATH_SMALL_LDS 1        /* fom_small_kernel<true>: one workgroup per sample, value vector in LDS */
+#define FINROM_FOM_PATH_SMALL_GLOBAL 2     /* fom_small_kernel<false>: value vector in the workspace */
+#define FINROM_FOM_PATH_INTERPRETER 3      /* fom_vm_kernel + fom_bwd_kernel (schedule interpreter) */
+#define FINROM_FOM_PATH_BAND_REGISTERS 4   /* fom_band_kernel: frontal band sweep, front in registers (m <= 12) */
+#define FINROM_FOM_PATH_BAND_LDS_4WAVE 5   /* fom_band_ldsw_kernel: post's window over four waves + LDS exchange (m = 16, 20) */
+#define FINROM_FOM_PATH_BAND_LDS_1WAVE 6   /* fom_band_lds_kernel: one-wave LDS window (A/B builds only) */
+int finrom_fom_last_path(finrom_fom_t h);
+int finrom_fom_set_small_max(finrom_fom_t h, int32_t small_max);
 
 /* ---- ROM: batched LSPG reduced solve ------------------------------------------------- *
  * Replaces AffineROMFin.forward_nine_param_reduced + .qoi_reduced

@@ -25,12 +25,12 @@ def test_oracle_reproduces_golden(problems):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("schedule", ["small-batch schedule", "interpreter"])
+@pytest.mark.parametrize("schedule", ["small-batch schedule", "throughput schedule"])
 @pytest.mark.parametrize("kind,key", [("five", "k5"), ("nine", "k9"), ("field", "fields")])
 def test_gpu_reproduces_golden(spaces, kind, key, schedule, monkeypatch):
     from bayesianinferencedl_amd.pairs import FinPairSolver
     import bayesianinferencedl_amd.engine as E
-    if schedule == "interpreter":                  # the golden batches are small: also check the throughput schedule
+    if schedule == "throughput schedule":          # the golden batches are small: also check the band sweep
         monkeypatch.setattr(E, "SMALL_MAX", 0)
     V = spaces(int(G["m"]))
     res = FinPairSolver(V, G["phi"], params=kind).solve_pairs(G[key], want_w=True, want_w_r=True)

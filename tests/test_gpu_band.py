@@ -1,8 +1,12 @@
-"""The frontal band sweep (csrc/fom_band.hip, front in registers) against the oracle and against the schedule interpreter it
-replaces on the throughput path: w and QoI <= 1e-10 relative for nodal fields and for five / nine fin conductivities, on
-every mesh the library has window sizes for, failure flags for indefinite operators, batch tails."""
-import os
+"""The frontal band sweep (csrc/fom_band.hip) against the oracle and against the schedule interpreter it replaces on the
+throughput path: w and QoI <= 1e-10 relative for nodal fields and for five / nine fin conductivities, on every mesh the library
+has window sizes for -- the front in registers (m = 4, 8, 12: fom_band_kernel) and the post's window over four waves with LDS as
+the exchange (m = 16, 20: fom_band_ldsw_kernel) -- failure flags for indefinite operators, batch tails.
 
+Every case ASSERTS WHICH KERNEL RAN (finrom_fom_last_path): the small-batch schedule takes batches of <= 512 samples (<= 4096
+when the value vector does not fit LDS, i.e. m >= 16), so a test that only sizes its batch "large" can silently compare
+fom_small_kernel with itself -- round 2's m = 16 / 20 cases did.  Here the threshold is moved out of the way on the handle
+(finrom_fom_set_small_max) and the path is checked after every call."""
 import numpy as np
 import pytest
 
@@ -10,58 +14,96 @@ from oracle import fin_oracle as O
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
+BAND_PATH = {4: "band_registers", 8: "band_registers", 12: "band_registers", 16: "band_lds_4wave", 20: "band_lds_4wave"}
 
 
 def _rel(a, b):
     return np.max(np.linalg.norm(a - b, axis=1) / np.linalg.norm(b, axis=1))
 
 
-@pytest.mark.parametrize("m", [4, 8, 12, 16, 20])      # 16, 20: the variant with the post's window in LDS
-def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
+def _throughput_engines(V, kinds=("field", "nine", "five")):
+    """(Fin on the band sweep, Fin on the interpreter), both with the small-batch schedule out of the way."""
     import bayesianinferencedl_amd.engine as E
     from bayesianinferencedl_amd.fom.forward_solve import Fin
-    prob, V = problems(m), spaces(m)
-    fo = O.FinOracle(prob)
-    rng = np.random.default_rng(10 + m)
-    S = 700                                               # beyond the small-batch schedule; not a multiple of 64
     fin = Fin(V)
     old = E.USE_BAND
     try:
         E.USE_BAND = False
         fin_i = Fin(V)                                    # interpreter-only engines (created lazily: force them now)
-        for params in ("field", "nine", "five"):
+        for params in kinds:
             assert fin_i._engine(params).band is None
+            fin_i._engine(params).set_small_max(0)
     finally:
         E.USE_BAND = old
-    for params, dim in (("field", prob.n), ("nine", 9), ("five", 5)):
-        X = np.exp(0.5 * rng.standard_normal((S, dim))) if params == "field" else rng.uniform(0.1, 10.0, (S, dim))
+    for params in kinds:
         eng = fin._engine(params)
         assert eng.band is not None, "band sweep not installed"
-        res = fin.forward_batch(X, want_w=True, params=None if params == "field" else params)
-        ref = fin_i.forward_batch(X, want_w=True, params=None if params == "field" else params)
-        assert fin_i._engine(params).band is None
-        assert (res["info"] == 0).all()
+        assert eng.last_path() == "none"
+        eng.set_small_max(0)
+    return fin, fin_i
+
+
+@pytest.mark.parametrize("m", [4, 8, 12, 16, 20])
+def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
+    prob, V = problems(m), spaces(m)
+    fo = O.FinOracle(prob)
+    rng = np.random.default_rng(10 + m)
+    S = 700                                               # 11 blocks of 64 lanes, the last one with 60 live lanes
+    fin, fin_i = _throughput_engines(V)
+    # samples checked against the oracle: first / last lane of a block, mid lanes of several blocks, the tail block
+    picks = (0, 1, 63, 64, 130, 257, 389, 511, 640, 699)
+    for params, dim in (("field", prob.n), ("nine", 9), ("five", 5)):
+        X = np.exp(0.5 * rng.standard_normal((S, dim))) if params == "field" else rng.uniform(0.1, 10.0, (S, dim))
+        kw = dict(want_w=True, params=None if params == "field" else params)
+        res = fin.forward_batch(X, **kw)
+        assert fin._engine(params).last_path() == BAND_PATH[m], fin._engine(params).last_path()
+        ref = fin_i.forward_batch(X, **kw)
+        assert fin_i._engine(params).last_path() == "interpreter"
+        assert (res["info"] == 0).all() and (ref["info"] == 0).all()
         assert _rel(res["w"], ref["w"]) < TOL and _rel(res["qoi"], ref["qoi"]) < TOL
         lift = {"field": lambda x: x, "nine": fo.nine_param_to_function, "five": fo.five_param_to_function}[params]
-        for s in (0, 1, 63, 64, S - 1):
+        for s in picks:
             w = fo.forward(lift(X[s]))
-            assert np.linalg.norm(res["w"][s] - w) < TOL * np.linalg.norm(w)
+            assert np.linalg.norm(res["w"][s] - w) < TOL * np.linalg.norm(w), (params, s)
             q = fo.qoi_operator(w)
-            assert np.linalg.norm(res["qoi"][s] - q) < TOL * np.linalg.norm(q)
+            assert np.linalg.norm(res["qoi"][s] - q) < TOL * np.linalg.norm(q), (params, s)
+        # QoI-only calls (the sample-pair path asks for no w) take the same kernel and give the same observables
+        res_q = fin.forward_batch(X, want_w=False, params=kw["params"])
+        assert fin._engine(params).last_path() == BAND_PATH[m]
+        assert np.array_equal(res_q["qoi"], res["qoi"])
 
 
-@pytest.mark.parametrize("m", [12, 20])
+@pytest.mark.parametrize("m", [12, 16, 20])
 def test_band_sweep_flags_indefinite_samples(spaces, m):
-    from bayesianinferencedl_amd.fom.forward_solve import Fin
-    V = spaces(m)
-    fin = Fin(V)
+    """A negative conductivity in every fin (the failure is seen by a FIN's sweep -- in the four-wave kernel by whichever wave
+    swept that fin) and one in the centre post only (seen by the post's sweep): both samples are flagged and NaN, nobody else
+    is, including their neighbours in the same wave; the second one sits in the tail block."""
+    fin, _ = _throughput_engines(spaces(m), kinds=("nine",))
     rng = np.random.default_rng(3)
     X = rng.uniform(0.5, 2.0, (600, 9))
     X[17] = -X[17]; X[599, 4] = -5.0
+    X[130, 7] = -3.0                                      # one fin only: in the four-wave kernel ONE wave sees this failure
     res = fin.forward_batch(X, want_w=True, params="nine")
-    assert fin._engine("nine").band is not None
+    assert fin._engine("nine").last_path() == BAND_PATH[m]
     bad = np.nonzero(res["info"])[0].tolist()
-    assert bad == [17, 599]
-    assert np.isnan(res["qoi"][17]).all() and np.isnan(res["w"][599]).all()
+    assert bad == [17, 130, 599]
+    for s in bad:
+        assert np.isnan(res["qoi"][s]).all() and np.isnan(res["w"][s]).all()
     good = np.setdiff1d(np.arange(600), bad)
     assert np.isfinite(res["qoi"][good]).all() and np.isfinite(res["w"][good]).all()
+
+
+@pytest.mark.parametrize("m,small_path,small_max", [(12, "small_lds", 512), (20, "small_global", 4096)])
+def test_dispatch_by_batch_size(spaces, m, small_path, small_max):
+    """finrom_fom_solve's dispatch, asserted: batches up to the handle's threshold take the small-batch schedule (value vector
+    in LDS at m = 12, in the workspace at m = 20), the next size up takes the band sweep; results agree to round-off."""
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    fin = Fin(spaces(m))
+    eng = fin._engine("nine")
+    rng = np.random.default_rng(8)
+    X = rng.uniform(0.1, 10.0, (small_max + 1, 9))
+    a = fin.forward_batch(X[:small_max], want_w=False, params="nine")
+    assert eng.last_path() == small_path
+    b = fin.forward_batch(X, want_w=False, params="nine")
+    assert eng.last_path() == BAND_PATH[m]
+    assert _rel(a["qoi"], b["qoi"][:small_max]) < 1e-12

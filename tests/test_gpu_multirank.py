@@ -31,3 +31,30 @@ def test_two_ranks_reproduce_the_single_process_outputs(params, extra):
     assert two["config"]["failed_samples"] == 0 and one["config"]["failed_samples"] == 0
     assert two["gathered_sha256"] == one["gathered_sha256"]
     assert two["value"] > 0 and two["scaling"] == "weak"
+
+
+def test_one_rank_rccl_process_group_and_device_gather():
+    """The `nccl` backend (= RCCL on ROCm) executed for real before the first multi-GPU run: one rank started by
+    torch.distributed.run (launched before anything touches the GPU), --force-pg creates the RCCL communicator with
+    device_id = cuda:0 and runs the per-step all_gather_into_tensor + barrier + all_reduce on DEVICE tensors at world = 1; the
+    gathered checksum must equal the plain single-process run's."""
+    common = ["--steps", "2", "--warmup", "1", "--cpu-samples", "0", "--no-profile", "--samples", "3000"]
+    plain = _bench(["--gpus", "1"] + common)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = ["--gpus", "1", "--backend", "nccl", "--force-pg"] + common
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_ARGV=json.dumps(argv)))
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    forced = json.loads(lines[0])
+    assert forced["process_group"] == {"backend": "nccl", "world": 1, "forced": True}
+    assert forced["gathered_sha256"] == plain["gathered_sha256"]
+    assert forced["config"]["failed_samples"] == 0 and forced["value"] > 0
+    # and without the launcher: bench.py --force-pg makes its own one-rank rendezvous
+    alone = _bench(argv)
+    assert alone["process_group"]["backend"] == "nccl" and alone["gathered_sha256"] == plain["gathered_sha256"]

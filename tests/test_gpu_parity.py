@@ -10,12 +10,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10
 
 
-@pytest.fixture(autouse=True, params=["small-batch schedule", "interpreter"])
+@pytest.fixture(autouse=True, params=["small-batch schedule", "throughput schedule"])
 def fom_schedule(request, monkeypatch):
     """Small batches take the latency-oriented FOM schedule (finrom_fom_set_small); every test here also runs with it
-    disabled, so that the throughput interpreter is checked on the same inputs."""
+    not installed, so that the throughput schedule -- the frontal band sweep on every mesh with a band plan (m <= 20), the
+    schedule interpreter otherwise and for the adjoint gradient -- is checked on the same inputs.  (Which kernel ran is
+    asserted where a test is ABOUT a kernel: tests/test_gpu_band.py, test_fwd_chunk_16_..., test_interpreter_forward_path_....)"""
     import bayesianinferencedl_amd.engine as E
-    if request.param == "interpreter":
+    if request.param == "throughput schedule":
         monkeypatch.setattr(E, "SMALL_MAX", 0)
     return request.param
 
@@ -332,13 +334,45 @@ def test_fwd_chunk_16_stream_gives_the_same_solution(problems, spaces, monkeypat
     X = rng.uniform(0.1, 10.0, (70, 9 if params == "nine" else 5))
     monkeypatch.setattr(E, "FWD_CHUNK", chunk)
     monkeypatch.setattr(E, "ROW_CACHE_SLOTS", cache)
+    monkeypatch.setattr(E, "USE_BAND", False)              # this test is about fom_vm_kernel<8|16>: no band sweep,
+    monkeypatch.setattr(E, "SMALL_MAX", 0)                 # no small-batch schedule (whatever the fixture chose)
     fin = Fin(get_space(40, m=m))
     res = fin.forward_batch(X, want_w=True, params=params)
     eng = fin._engine(params)
+    assert eng.last_path() == "interpreter"
     assert eng.fused == (cache == 17) and eng.cache_slots == (12 if cache == 17 else cache)
     lift = fo.nine_param_to_function if params == "nine" else fo.five_param_to_function
     W = np.array([fo.forward(lift(X[i])) for i in range(8)])
     assert rel(np.asarray(res["w"])[:8], W) < TOL
+
+
+def test_interpreter_forward_path_on_a_mesh_without_band_plan_sizes(problems, fom_schedule):
+    """m = 24 (n = 5785): the library has no window sizes for this mesh (finrom_fom_set_band answers UNSUPPORTED), so the
+    throughput path is the schedule interpreter fom_vm_kernel + fom_bwd_kernel -- the one forward-path test on that kernel
+    for a mesh where it is the PRODUCT's path; field, nine and five inputs, batch tail, against the oracle."""
+    if fom_schedule != "throughput schedule":
+        pytest.skip("one run is enough: the test removes the small-batch schedule itself")
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.fom.thermal_fin import get_space
+    m = 24
+    prob = problems(m)
+    fo = O.FinOracle(prob)
+    fin = Fin(get_space(None, m=m))
+    rng = np.random.default_rng(24)
+    S = 150
+    for params, dim in (("field", prob.n), ("nine", 9), ("five", 5)):
+        X = np.exp(0.5 * rng.standard_normal((S, dim))) if params == "field" else rng.uniform(0.1, 10.0, (S, dim))
+        eng = fin._engine(params)
+        assert eng.band is None
+        res = fin.forward_batch(X, want_w=True, params=None if params == "field" else params)
+        assert eng.last_path() == "interpreter"
+        assert (res["info"] == 0).all()
+        lift = {"field": lambda x: x, "nine": fo.nine_param_to_function, "five": fo.five_param_to_function}[params]
+        for s_ in (0, 63, 64, 127, 128, S - 1):
+            w = fo.forward(lift(X[s_]))
+            assert np.linalg.norm(res["w"][s_] - w) < TOL * np.linalg.norm(w), (params, s_)
+            q = fo.qoi_operator(w)
+            assert np.linalg.norm(res["qoi"][s_] - q) < TOL * np.linalg.norm(q), (params, s_)
 
 
 def test_create_rejects_corrupt_descriptors(spaces):

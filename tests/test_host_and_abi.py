@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in finrom.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib.finrom_version.restype = ctypes.c_int
-    assert lib.finrom_version() == 8
+    assert lib.finrom_version() == _ffi.ABI_VERSION == 9
 
 
 def test_missing_library_fails_loudly(monkeypatch):

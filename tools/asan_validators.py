@@ -59,6 +59,8 @@ def spy_rom_create(dref, href):
     call = lambda: real_rom_create(C.byref(d), C.byref(h))
     tweak(d.term_p, 0, d.P + 1, call, "rom_create: theta index out of range")
     tweak(d.row_ptr, 1, -1, call, "rom_create: row_ptr not monotone")
+    row = next(i for i in range(d.n) if d.row_ptr[i + 1] - d.row_ptr[i] >= 2)
+    tweak(d.term_p, d.row_ptr[row] + 1, d.term_p[d.row_ptr[row]], call, "rom_create: a row lists the same theta index twice")
     old = d.r; d.r = 209; expect_error("rom_create: basis too wide", call()); d.r = old
     return real_rom_create(dref, href)
 
@@ -80,4 +82,71 @@ expect_error("fom_solve: null handle", lib.finrom_fom_solve(None, None, 4, None,
 expect_error("rom_solve: null handle", lib.finrom_rom_solve(None, None, 4, None, None, None, None, None, None))
 expect_error("solve_pairs: null handles", lib.finrom_solve_pairs(None, None, None, None, 1, None, None, None, None, None, None, None, None))
 expect_error("fom_set_band: null", lib.finrom_fom_set_band(None, None))
+
+# ---- the band descriptor (finrom_fom_set_band's host-only validator, exported as finrom_fom_band_validate): the product's own
+# descriptors for every mesh with a band plan and every parameter kind must pass, one-field corruptions must be rejected -------
+import scipy.sparse as sp                                                    # noqa: E402
+from bayesianinferencedl_amd.engine import FomEngine                         # noqa: E402
+
+
+def band_cases(m, kinds, corrupt):
+    Vm = get_space(None, m=m)
+    ops = Vm.operators()
+    bp = ops.band_plan()
+    assert bp is not None, m
+    fin = Fin(Vm)
+    for kind in kinds:
+        W = {"field": ops.W_field, "nine": sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9)),
+             "five": sp.csr_matrix(ops.W_field @ sp.csr_matrix(ops.N9 @ ops.E59))}[kind]
+        xdim = W.shape[1]
+        d, keep, _ = FomEngine.band_descriptor(bp, xdim, ops.robin_vals, W, ops.F, fin.B_obs)
+        call = lambda: lib.finrom_fom_band_validate(C.byref(d), ops.n, xdim, fin.n_obs)
+        rc = call()
+        assert rc == 0, (m, kind, lib.finrom_last_error())
+        cases.append((f"band descriptor m={m} {kind}: accepted", rc))
+        if not corrupt:
+            continue
+        G = bp.G
+        nift = d.nif * (d.nif + 1) // 2
+        tweak(d.abmap, 7, d.nAB, call, "band: abmap out of range")
+        tweak(d.abmap, 3 * G - 1, -1, call, "band: abmap negative")
+        tweak(d.act, 5, 1 << d.NX, call, "band: act has a bit beyond NX")
+        p_act = next(p_ for p_ in range(d.npost) if d.act[p_] != 0)
+        tweak(d.act, p_act, 0, call, "band: act disagrees with lx_ptr")
+        tweak(d.lx_ptr, d.npost, d.nLx + 1, call, "band: lx_ptr does not end at nLx")
+        tweak(d.ent_extra, 3, d.NX + 1, call, "band: ent_extra beyond NX")
+        tweak(d.schur_off, 1, d.nAB + 3, call, "band: schur_off out of range")
+        tweak(d.schur_off, nift, d.schur_off[0], call, "band: two fins share a Schur slot")
+        tweak(d.schur_off, 1, d.schur_off[0], call, "band: Schur slot repeated within a fin")
+        tweak(d.iface_elim, 0, 0, call, "band: interface node is not a post node")
+        tweak(d.iface_elim, 1, ops.n, call, "band: iface_elim out of range")
+        tweak(d.perm, 0, d.perm[1], call, "band: perm is not a permutation")
+        tweak(d.obs_idx, 0, ops.n, call, "band: observation index out of range")
+        tweak(d.ab_idx, 0, xdim, call, "band: parameter index out of range")
+        tweak(d.ecp_off, 0, d.nAB, call, "band: ecp_off out of range")
+        tweak(d.ecp_slot, 0, d.NX, call, "band: ecp_slot out of range")
+        # a logical value slot de-duplicated onto a slot a fin writes to would be a second reader of that slot
+        tweak(d.abmap, 0, d.schur_off[0], call, "band: a Schur slot is also somebody's plain value slot")
+        for field in ("abmap", "ab_ptr", "ab_c0", "Fg", "act", "lx_ptr", "ent_extra", "ecp_ptr", "ecp_off", "schur_off", "iface_elim",
+                      "perm", "obs_ptr", "obs_idx"):
+            ptype = type(getattr(d, field))
+            addr = C.cast(getattr(d, field), C.c_void_p).value      # (the attribute is a VIEW of the field: keep the address)
+            setattr(d, field, ptype())                  # NULL pointer
+            try:
+                expect_error(f"band: {field} is NULL", call())
+            finally:
+                setattr(d, field, C.cast(addr, ptype))
+        for field, val in (("npf", d.NSF - 1), ("npost", d.NSP - 1), ("nif", d.nif + 1), ("NSP", 15), ("nAB", 0)):
+            old = getattr(d, field); setattr(d, field, val)
+            try:
+                expect_error(f"band: {field} = {val}", call())
+            finally:
+                setattr(d, field, old)
+        assert call() == 0, ("descriptor not restored", lib.finrom_last_error())
+
+
+band_cases(12, ("five",), corrupt=True)
+band_cases(20, ("field",), corrupt=True)
+for m_ in (4, 8, 16):
+    band_cases(m_, ("field", "nine", "five"), corrupt=False)
 print(f"ASAN-VALIDATORS-OK {len(cases)} cases")
