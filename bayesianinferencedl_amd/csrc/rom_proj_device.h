@@ -634,13 +634,154 @@ __device__ __forceinline__ void fused_solve_mw(const RomDev& p, d4 (&acc)[(NB * 
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same idea for ONE wave (r <= 80, factor == 2, only qoi_r wanted -- what finrom_solve_pairs asks for): the epilogue of the
+// single-wave kernel used to be chol_tiles (16 shuffle steps per block row over ALL its tiles) + solve_tiles (2 r dependent
+// pivot steps): ~8.5 k vector instructions per sample, and every fp64 vector instruction also costs the partner wave's MFMAs
+// pipe time.  Here, per block row kb:
+//   (a) only the DIAGONAL tile goes through the 16 shuffle steps, applied to [A_kk | I]: leaves U_kk and M = U_kk^-T;
+//   (b) U(kb, tj) = M A(kb, tj) for the tiles right of it and Z_kb = M G_kb for the extra column: 4 MFMAs per tile (M is
+//       built transposed, which is its A-operand layout);
+//   (c) trailing update T(ti, tj) -= U(kb, ti)^T U(kb, tj) and G_ti -= U(kb, ti)^T Z_kb on the matrix cores (operands = the
+//       registers of U themselves, as in chol_tiles).
+// G = [B_r | (B_obs Phi)^T] (1 + n_obs <= 16 columns: ONE extra tile column), Z = U^-T G, and
+//   qoi_r = (B_obs Phi) U^-1 U^-T B_r = Z[:, 1:]^T Z[:, 0]      (rom :304, :323-333)
+// needs no backward substitution.  ~2.4 k vector instructions + 180 MFMAs per sample at r = 80.
+// ---------------------------------------------------------------------------------------
+constexpr int ROM_SW_LDS = 16 * 5;      // doubles of LDS per wave (B_r)
+template <int NB>
+__device__ __forceinline__ int fused_solve_sw(const RomDev& p, d4 (&acc)[NB * (NB + 1) / 2], const double (&bacc)[NB], int q, int c,
+                                              double* __restrict__ mt, double& qout) {
+  // The extra column is formed LEFT-looking -- G_kb -= sum_{j < kb} U(j, kb)^T Z_j when block row kb is reached -- so that at most
+  // kb + 1 of its tiles are live beside the shrinking block triangle: 16 tiles at the peak instead of 20 (the kernel has to stay
+  // at <= 200 VGPRs to share a SIMD with a wave of the FOM band sweep).
+  d4 z[NB];
+  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.obs_phi), 0, p.n_obs * p.r * 8, 0x00020000);
+  const int ovoff = ((c - 1) * p.r + q) * 8;             // row q of observation c - 1 (c == 0: far out of range)
+  // B_r waits in LDS until its block row is reached: 10 registers the trailing updates need
+  double* __restrict__ bl = mt;
+  if (q == 0) sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; bl[16 * b + c] = bacc[b]; });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // padding rows / columns (>= r) of psi^T psi are zero: unit diagonal
+#pragma unroll
+  for (int t = 0; t < NB; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (q + 4 * g == c && 16 * t + c >= p.r) acc[tidx<NB>(t, t)][g] = 1.0;
+  int bad = 0;
+  sfor<0, NB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+    // G_kb = [B_r | (B_obs Phi)^T | 0] rows of this block: column 0 = B_r, columns 1 .. n_obs = rows of B_obs Phi
+    d4 e[1];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + q + 4 * g;
+      // (buffer load: one per-lane offset for the whole epilogue, the block row in the scalar offset; lane column 0 and the
+      // columns beyond n_obs address outside the table and read 0)
+      double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ores, ovoff, (16 * kb + 4 * g) * 8, 0));
+      if (row >= p.r) v = 0.0;
+      if (c == 0) v = bl[row];
+      e[0][g] = v;
+    }
+    // ... minus what the block rows above contribute: a chain of 4 kb MFMAs on one accumulator (each waits for its
+    // predecessor; the partner wave has the pipe meanwhile), its last wait behind the diagonal tile's factorisation
+    sfor<0, kb>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (j > 0 || g > 0) mfma_drain(e);
+        const double ua = acc[tidx<NB>(j, kb)][g], zb = z[j][g];
+        asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]" : "+v"(e[0]) : "v"(ua), "v"(zb));
+      }
+    });
+    // (a) the 16 elimination steps on the diagonal tile; M^T is carried instead of M (COLUMN operations on F = E^T: lane
+    // column c plays row c of E), because the C/D layout of M^T IS the A-operand layout of M -- F[g] at lane (q, c) =
+    // M[c][4 g + q] -- so M needs no transposition through LDS (whose allocation would cost the band sweep, which shares the CU
+    // and wants 37 KB per wave, a quarter of its waves)
+    double Am[4];
+    {
+      d4& D = acc[tidx<NB>(kb, kb)];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Am[g] = (q + 4 * g == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int gs = 0; gs < 4; ++gs)
+#pragma unroll 1
+        for (int qs = 0; qs < 4; ++qs) {
+          const int st = 4 * gs + qs;
+          const double piv = read_lane_f64(D[gs], qs * 16 + st);
+          bad |= !(piv > 0.0);
+          double rinv = __builtin_amdgcn_rsq(piv);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+          D[gs] *= (q == qs) ? rinv : 1.0;                 // row st of U is final
+          const double rvD = __shfl(D[gs], qs * 16 + c);   // U[st][c]
+          const double mcol = (c > st) ? rvD : 0.0, scol = (c == st) ? rinv : 1.0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (g <= gs) {                                 // column st of M^T is zero below row st
+              Am[g] *= scol;
+              Am[g] = fma(-mcol, __shfl(Am[g], q * 16 + st), Am[g]);
+            }
+            if (g >= gs) {                                 // rows below the pivot only (gs is unrolled)
+              const double v = __shfl(D[gs], qs * 16 + ((q + 4 * g) & 15));
+              const double m = (q + 4 * g > st) ? v : 0.0;
+              D[g] = fma(-m, rvD, D[g]);
+            }
+          }
+        }
+    }
+    if constexpr (kb > 0) mfma_drain(e);
+    // (b) one tile at a time: four dependent MFMAs, the wait between them covers the same-accumulator hazard
+    auto solve_tile = [&](d4& T) {
+      double b[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) b[g] = T[g];             // plain 64-bit registers: legal MFMA sources (see chol_tiles)
+      d4 n[1] = {(d4){0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(n[0]) : "v"(Am[g]), "v"(b[g]));
+        mfma_drain(n);
+      }
+      T = n[0];
+    };
+    sfor<kb + 1, NB>([&](auto jc) { solve_tile(acc[tidx<NB>(kb, decltype(jc)::value)]); });
+    solve_tile(e[0]);
+    z[kb] = e[0];
+    if constexpr (kb + 1 < NB) {                           // (c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // (operands: element g of the tiles of block row kb, as 64-bit "v" inputs -- the compiler picks legal, even-aligned
+        // pairs, and coalesces them with the tuples' sub-registers when it can; the kernel is register-bound)
+#pragma unroll
+        for (int ti = kb + 1; ti < NB; ++ti)
+#pragma unroll
+          for (int tj = ti; tj < NB; ++tj)
+            asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]"
+                         : "+v"(acc[tidx<NB>(ti, tj)]) : "v"((double)acc[tidx<NB>(kb, ti)][g]), "v"((double)acc[tidx<NB>(kb, tj)][g]));
+        mfma_drain(acc);
+      }
+    }
+  });
+  // qoi_r[o] = sum_rows Z[row][o + 1] Z[row][0]: column 0 of a row lives in lane (q, 0) of the row's group
+  double part = 0.0;
+  sfor<0, NB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) part = fma(z[kb][g], __shfl(z[kb][g], q * 16), part);
+  });
+  part += __shfl_xor(part, 16);
+  part += __shfl_xor(part, 32);
+  qout = part;                                             // lane c = o + 1 (any row group): qoi_r[o]
+  return bad;
+}
+
 template <int NB, int NW, int W, bool SK = false>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                               int* __restrict__ info, double* __restrict__ w_r = nullptr,
                                               double* __restrict__ qoi_r = nullptr, double* slab = nullptr,
                                               const double* __restrict__ theta_s = nullptr, const int* __restrict__ kpat = nullptr,
-                                              int kpart = 0, int kparts = 1, const RomGradArgs* ga = nullptr) {
+                                              int kpart = 0, int kparts = 1, const RomGradArgs* ga = nullptr, double* mt_lds = nullptr) {
   // kparts > 1 (NW == 1, small batches): the sample's k-steps are split over the kparts waves of the workgroup, the partial
   // block triangles are summed through LDS (`slab`) in a fixed order and wave 0 alone runs the epilogue
   constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
@@ -723,8 +864,12 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     }
   }
   int bad = 0;
+  // factor == 2 with nothing but qoi_r wanted (the sample-pair path): factorisation, both substitutions and the reduced QoI as
+  // MFMA-form panel operations (fused_solve_sw), after B_r below
+  const bool qoi_only = NW == 1 && NB <= 5 && !SK && factor == 2 && w_r == nullptr && qoi_r != nullptr && mt_lds != nullptr &&
+                        p.n_obs <= 15;
   if constexpr (NW == 1 && NB <= 6) {
-    if (factor) {      // A_r = U^T U in registers; what is written below is then U^T (= L, packed by columns)
+    if (factor && !qoi_only) {      // A_r = U^T U in registers; what is written below is then U^T (= L, packed by columns)
       bad = chol_tiles<NB>(acc, q, c, p.r);
       if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
     }
@@ -786,6 +931,15 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
       x += __shfl_xor(x, 32);
       bacc[b] = x;                               // B_r[16 b + c], the same in all four row groups
       if (!fused_solve && q == 0) Br[s * p.rp + 16 * b + c] = x;
+    }
+    if constexpr (NW == 1 && NB <= 5 && !SK) {
+      if (qoi_only) {
+        double qv;
+        bad = fused_solve_sw<NB>(p, acc, bacc, q, c, mt_lds, qv);
+        if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
+        if (lane >= 1 && lane <= p.n_obs) qoi_r[s * p.n_obs + lane - 1] = bad ? __builtin_nan("") : qv;
+        return;
+      }
     }
     if constexpr (NW == 1 && (NB <= 5 || SK)) {
       if (fused_solve) {
@@ -899,6 +1053,7 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
   constexpr int WPB = NW > 4 ? NW : 4;
   static_assert(NW == 1 || NW == 4 || NW == 8, "a workgroup is one sample when its waves share the slab (uniform early exit, barriers)");
   __shared__ double th[WPB][32];
+  __shared__ double mt_sw[NW == 1 && NB <= 5 ? WPB * ROM_SW_LDS : 1];      // fused_solve_sw: B_r, per wave
   __shared__ double slab_lds[NW > 1 ? (3 * NB * 64 > fused_mw_lds_doubles<NB>() ? 3 * NB * 64 : fused_mw_lds_doubles<NB>()) : 1];
   double* slab = slab_lds;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: say so (scalar branches below)
@@ -915,7 +1070,8 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));     // provably in SGPRs
   const double* theta_u = theta_s;
   if constexpr (NW == 1) {
-    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r, nullptr, theta_s, kpat);
+    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r, nullptr, theta_s, kpat, 0, 1, nullptr,
+                            NB <= 5 ? mt_sw + wave * ROM_SW_LDS : nullptr);
   } else if constexpr (NW == 4) {
     switch (wave % 4) {
       case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;

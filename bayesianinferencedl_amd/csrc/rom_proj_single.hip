@@ -1,13 +1,16 @@
 // The single-wave projection kernels (r <= 80: one wave owns a sample, factorisation + substitutions in registers) in their
-// own translation unit, built at -O2 (see _build.py): hipcc's -O3 inflates their register use (r = 80: 188 -> 256 VGPRs +
-// scratch), and they must stay small enough to share a SIMD with the FOM interpreter's waves: 2 x 192 registers of the
-// r = 80 kernel and 2 x 56 of the interpreter fill a SIMD's 512 exactly.
+// own translation unit, built at -O2 (see _build.py): hipcc's -O3 inflates their register use (r = 80: 196 -> 256 VGPRs +
+// scratch), and they must stay small enough to share a SIMD with a wave of the FOM band sweep.
 #include "rom_proj_device.h"
 
 namespace finrom {
 
+// amdgpu_num_vgpr(100): on gfx90a+ the attribute counts the unified file in halves, i.e. this caps the kernel at 200
+// architectural VGPRs (hipcc otherwise stops at whatever fits two waves per SIMD -- 202 at r = 80, no spills either way):
+// 200 + the band sweep's 312 (256 + 50 accumulation registers, granule 8) fill a SIMD's 512 exactly, so that a projection wave
+// and a sweep wave can share a SIMD; at 208 they could not, and the sweep would have to wait for a SIMD to drain completely.
 template <int NB>
-__global__ __launch_bounds__(256, 2) void rom_proj_single_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(100))) void rom_proj_single_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                                  double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                                  int* __restrict__ info, double* __restrict__ w_r,
                                                                  double* __restrict__ qoi_r, const int* __restrict__ kpat) {

@@ -346,6 +346,35 @@ def test_fwd_chunk_16_stream_gives_the_same_solution(problems, spaces, monkeypat
     assert rel(np.asarray(res["w"])[:8], W) < TOL
 
 
+@pytest.mark.parametrize("m,r", [(4, 8), (12, 17), (12, 33), (12, 50), (12, 64), (12, 80)])
+def test_rom_qoi_only_epilogue_parity(problems, spaces, m, r, fom_schedule):
+    """r <= 80 with nothing but the reduced QoI wanted (what finrom_solve_pairs asks for): the single-wave kernel's MFMA-form
+    epilogue (rom_proj_device.h::fused_solve_sw -- diagonal tiles by shuffle steps, panels and the extra column
+    [B_r | (B_obs Phi)^T] by MFMA, qoi_r = Z[:, 1:]^T Z[:, 0], no backward substitution) against the oracle and against the
+    kernel's own solve-based epilogue (want_w=True: chol_tiles + solve_tiles); batch tail included (130 = 32 x 4 + 2)."""
+    if fom_schedule != "throughput schedule":
+        pytest.skip("ROM only: one run")
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    prob = problems(m); V = spaces(m)
+    phi = oracle_basis(prob, r)
+    ro = O.AffineROMOracle(prob, phi)
+    rng = np.random.default_rng(40 + r)
+    TH = rng.uniform(0.1, 10.0, (130, 9))
+    rom = AffineROMFin(V, None, phi)
+    a = rom.forward_nine_param_reduced_batch(TH, want_w=False)          # QoI only: the MFMA-form epilogue
+    b = rom.forward_nine_param_reduced_batch(TH, want_w=True)           # with w_r: factorisation + two substitutions
+    assert "w_r" not in a and (a["info"] == 0).all() and (b["info"] == 0).all()
+    assert rel(a["qoi_r"], b["qoi_r"]) < 1e-11
+    Q = np.array([ro.qoi_reduced(ro.forward_nine_param_reduced(TH[i])) for i in (0, 1, 2, 3, 4, 63, 64, 127, 128, 129)])
+    assert rel(a["qoi_r"][[0, 1, 2, 3, 4, 63, 64, 127, 128, 129]], Q) < TOL
+    # an indefinite reduced operator cannot occur (A_r = psi^T psi), a singular one can: theta = 0 kills every conduction term
+    TH[5] = 0.0; TH[129] = np.nan
+    c = rom.forward_nine_param_reduced_batch(TH, want_w=False)
+    assert c["info"][129] != 0 and np.isnan(c["qoi_r"][129]).all()
+    good = np.setdiff1d(np.arange(130), [5, 129])
+    assert np.array_equal(c["qoi_r"][good], a["qoi_r"][good]) and (c["info"][good] == 0).all()
+
+
 def test_interpreter_forward_path_on_a_mesh_without_band_plan_sizes(problems, fom_schedule):
     """m = 24 (n = 5785): the library has no window sizes for this mesh (finrom_fom_set_band answers UNSUPPORTED), so the
     throughput path is the schedule interpreter fom_vm_kernel + fom_bwd_kernel -- the one forward-path test on that kernel

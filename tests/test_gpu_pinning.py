@@ -83,6 +83,19 @@ def test_reference_recipe_basis_conditioning(problems, spaces):
         # the observables and Phi w_r much better; the parity metric is 1e-10 on these two
         assert worst_q < 1e-10 and worst_w < 1e-10, (projection, worst_q, worst_w, max(conds))
     assert max(conds) > 1e9, max(conds)                    # the test really sits in the ill-conditioned regime
+    # the same regime through the QoI-only epilogues, which never form w_r: qoi_r = Z[:, 1:]^T Z[:, 0] with Z = U^-T [B_r | C^T]
+    # (r = 80: one wave, fused_solve_sw; r = 81 with the sample-pair path's arguments keeps the factor + substitution kernels)
+    phi80 = np.ascontiguousarray(phi[:, :80])
+    ro80 = O.AffineROMOracle(prob, phi80)
+    res = AffineROMFin(V, None, phi80).forward_nine_param_reduced_batch(theta, want_w=False)
+    assert (res["info"] == 0).all()
+    worst, c80 = 0.0, []
+    for s in range(0, S, 7):
+        w_r, A_r, _, _ = ro80.forward_nine_param_reduced(theta[s], True)
+        c80.append(np.linalg.cond(A_r))
+        q = ro80.qoi_reduced(w_r)
+        worst = max(worst, np.linalg.norm(res["qoi_r"][s] - q) / np.linalg.norm(q))
+    assert worst < 1e-10 and max(c80) > 1e9, (worst, max(c80))
 
 
 def test_dense_lspg_helpers_of_the_product(problems, spaces):
