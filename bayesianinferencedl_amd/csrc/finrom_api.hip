@@ -609,6 +609,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (!rc) rc = up(h->owned, &b.obs_w, a->obs_w, nobsnz);
   if (rc) return rc;
   b.on = getenv("FINROM_BAND_TIMING") != nullptr ? 2 : 1;      // 2: block 0 reports its phase clocks in sample 0's QoI (diagnostic)
+  if (getenv("FINROM_BAND_NOMEM") != nullptr) b.on |= 4;       // timing experiment (m <= 12 kernel): no L / y / w traffic, garbage results
   h->band = b;
   return 0;
 }

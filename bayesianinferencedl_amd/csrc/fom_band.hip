@@ -781,7 +781,9 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __re
   const int lane = threadIdx.x;
   const int64_t blk = blockIdx.x;
   double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;
-  Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000), lane * 8};
+  // (FINROM_BAND_NOMEM, timing experiment, results are garbage: the buffer ends behind the value slots, so the stores of L, y, w
+  // are dropped and their loads return 0 by the hardware's range check -- the sweep's instructions without its HBM stream)
+  Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, ((p.on & 4) ? p.offL : p.gsize) * 512, 0x00020000), lane * 8};
   double* xs = xlds + lane;
   const PostTables T{act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off};
   int bad = 0;

@@ -257,7 +257,9 @@ __device__ __forceinline__ void proj_main_uniform(const RomDev& p, const int* __
   const c_f64_p theta_s = (c_f64_p)(unsigned long long)theta_g;
   const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.tvu), 0, p.tvu_bytes, 0x00020000);
   const int voff = (q * p.rp + c) * 8;
-  const int rowb = 4 * p.rp * 8;                         // bytes per slot (4 rows)
+  // bytes per slot (4 rows).  FINROM_CLOCK_PROBE=2 (timing experiment, results are garbage): every table fetch reads slot 0 --
+  // same instructions, no L2 / fabric traffic: what the kernel loses beside the FOM sweep with and without its table stream
+  const int rowb = p.clock_probe == 2 ? 0 : 4 * p.rp * 8;
   auto ldt = [&](int slot, auto bc) -> double {
     constexpr int b = decltype(bc)::value;
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * b, slot * rowb, 0));
