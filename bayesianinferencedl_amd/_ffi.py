@@ -53,7 +53,8 @@ class FomBandDesc(C.Structure):
                 ("act", c_i32p), ("lx_ptr", c_i32p), ("ent_extra", c_i32p),
                 ("ecp_ptr", c_i32p), ("ecp_slot", c_i32p), ("ecp_off", c_i32p),
                 ("schur_off", c_i32p), ("iface_elim", c_i32p), ("perm", c_i32p),
-                ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p)]
+                ("obs_ptr", c_i32p), ("obs_idx", c_i32p), ("obs_w", c_f64p),
+                ("qoi_FgQ", c_f64p), ("qoi_row_fin", c_i32p), ("qoi_obs_ptr", c_i32p), ("qoi_obs_idx", c_i32p), ("qoi_obs_w", c_f64p)]
 
 
 c_f32p = C.POINTER(C.c_float)
@@ -123,7 +124,7 @@ SIGNATURES = {
 ABI_VERSION = 9
 # finrom_fom_last_path codes (include/finrom.h)
 FOM_PATHS = {0: "none", 1: "small_lds", 2: "small_global", 3: "interpreter", 4: "band_registers", 5: "band_lds_4wave",
-             6: "band_lds_1wave"}
+             6: "band_lds_1wave", 7: "band_registers_qoi", 8: "band_lds_4wave_qoi"}
 
 _lib = None
 

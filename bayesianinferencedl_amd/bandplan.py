@@ -291,10 +291,13 @@ class BandPlan:
         return abmap.astype(np.int32), c0p, ptrp.astype(np.int32), idxp, wp
 
     # ------------------------------------------------------------------------------------------------------------------
-    def replay(self, AB, F):
+    def replay(self, AB, F, qoi_only=None):
         """NumPy execution of the plan with the device kernel's data flow (cyclic window slots, extras, fin Schur targets,
         stored L, backward substitution).  AB: assembled value slots [nAB] of one sample; F: load vector over dofs.
-        Returns w over dofs.  Test infrastructure for the tables -- the product path is csrc/fom_band.hip."""
+        Returns w over dofs.  Test infrastructure for the tables -- the product path is csrc/fom_band.hip.
+        qoi_only = (FgQ, row_fin, qptr, qidx, qw) (engine.FomEngine.qoi_only_tables): the kernel's QoI-only form instead -- the
+        fins' sweeps carry their observation row's weights as right-hand side, store nothing and have no backward sweep --
+        and the observables [n_obs] are returned."""
         AB = np.array(AB, dtype=np.float64, copy=True)
         n = self.n
         L = np.zeros(self.nL); Lx = np.zeros(max(self.nLx, 1)); y = np.zeros(n)
@@ -329,7 +332,9 @@ class BandPlan:
                 if t >= B:
                     v = (t - B) % NS
                     win[u, v] += AB[3 * g + 2]; win[v, u] = win[u, v]
-                if is_post or t < seg.npiv:
+                if qoi_only is not None:
+                    yw[u] += qoi_only[0][g]                # FgQ: the row's weights on a fin's segment nodes, the load on the post's
+                elif is_post or t < seg.npiv:
                     yw[u] += Fe[seg.e0 + t] if (is_post or t < seg.npiv) else 0.0
                 if is_post:
                     for c in range(self.ecp_ptr[t], self.ecp_ptr[t + 1]):
@@ -346,9 +351,10 @@ class BandPlan:
                 for s_ in range(1, NS):
                     l[s_] = win[(u + s_) % NS, u] * inv
                 base = seg.L0 + p * NS
-                L[base:base + B] = l[1:]; L[base + B] = inv
                 yp = yw[u] * inv
-                y[seg.e0 + p] = yp
+                if is_post or qoi_only is None:            # (QoI-only: nothing of a fin's factor or y is kept)
+                    L[base:base + B] = l[1:]; L[base + B] = inv
+                    y[seg.e0 + p] = yp
                 for s_ in range(1, NS):
                     a = (u + s_) % NS
                     yw[a] -= l[s_] * yp
@@ -371,11 +377,13 @@ class BandPlan:
                     enter(p + NS)
             return win, yw
 
+        gfun = []                                         # per fin: the functional's weights on the interface values
         for f, seg in enumerate(self.fin_segs):
             win, yw = sweep(seg, False)
             for t, s_, off in self.schur_target[f]:
                 a, b_ = (seg.npiv + t) % seg.NS, (seg.npiv + s_) % seg.NS
                 AB[off] += win[a, b_]
+            gfun.append([yw[(seg.npiv + t) % seg.NS] for t in range(seg.ntot - seg.npiv)])
         sweep(self.post_seg, True)
 
         # backward substitution, post first (reverse elimination order), then the fins
@@ -404,6 +412,14 @@ class BandPlan:
                 if is_post and self.ent_extra[p]:
                     Wx[self.ent_extra[p] - 1] = acc
         bsweep(self.post_seg, True)
+        if qoi_only is not None:
+            _, row_fin, qptr, qidx, qw = qoi_only
+            q = np.zeros(len(row_fin))
+            for o, f in enumerate(row_fin):
+                q[o] = sum(qw[t] * w[qidx[t]] for t in range(qptr[o], qptr[o + 1]))
+                if f >= 0:
+                    q[o] += sum(gfun[f][t] * w[self.iface_elim[f][t]] for t in range(len(gfun[f])))
+            return q
         for f, seg in enumerate(self.fin_segs):
             bsweep(seg, False, f)
         out = np.empty(n); out[self.perm] = w

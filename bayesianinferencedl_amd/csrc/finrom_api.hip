@@ -335,7 +335,7 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
   static const bool env_no_band = getenv("FINROM_NO_BAND") != nullptr;
   if (h->band.on && !env_no_band) {
     const BandDev& b = h->band;
-    h->last_path = band_path(b);
+    h->last_path = band_path(b, w == nullptr);
     const int64_t limit = fom_chunk_samples(d, &b);
     const int64_t npieces = (S + limit - 1) / limit;
     const int64_t chunk = npieces <= 1 ? limit : ((S + npieces - 1) / npieces + 63) / 64 * 64;
@@ -349,7 +349,7 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
         if ((rc = launch_fom_assemble(h->band_asm, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
       }
       if (stages & 2) {
-        if ((rc = launch_fom_band(b, (double*)h->Gw.p, nblk, Sc, qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
+        if ((rc = launch_fom_band(b, (double*)h->Gw.p, nblk, Sc, qoi ? qoi + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st, w == nullptr))) return rc;
         if (w && (rc = launch_unpack((const double*)h->Gw.p, Sc, d.n, b.gsize, b.offY, b.perm, w + s0 * d.n, st))) return rc;
       }
     }
@@ -555,6 +555,43 @@ static int validate_band(const finrom_fom_band_desc* a, int n, int xdim, int n_o
     if (a->obs_ptr[d.n_obs] > 0 && (!a->obs_idx || !a->obs_w)) return bad("table pointer (null)");
     for (int t = 0; t < a->obs_ptr[d.n_obs]; ++t) if (a->obs_idx[t] < 0 || a->obs_idx[t] >= n) return bad("obs_idx");
   }
+  // the fins' sweeps do not carry a load on their own nodes over to the interface nodes' right-hand sides
+  for (int f = 0; f < a->nfins; ++f)
+    for (int t = 0; t < a->npf + a->nif; ++t)
+      if (a->Fg[f * (a->npf + a->nif) + t] != 0.0) { set_error("fom_set_band: load on a fin's segment nodes is not supported by the sweep"); return FINROM_ERR_UNSUPPORTED; }
+  // QoI-only tables: the same operator as obs_*, entry by entry
+  const int nq = (a->qoi_FgQ != nullptr) + (a->qoi_row_fin != nullptr) + (a->qoi_obs_ptr != nullptr);
+  if (nq != 0) {
+    if (nq != 3 || d.n_obs <= 0) return bad("QoI-only tables (all or none)");
+    const int post_e0 = a->nfins * a->npf, post_g0 = a->nfins * (a->npf + a->nif), ntot = a->npf + a->nif;
+    if (a->qoi_obs_ptr[0] != 0) return bad("qoi_obs_ptr");
+    for (int o = 0; o < d.n_obs; ++o) if (a->qoi_obs_ptr[o + 1] < a->qoi_obs_ptr[o]) return bad("qoi_obs_ptr");
+    const int nqz = a->qoi_obs_ptr[d.n_obs];
+    if (nqz > 0 && (!a->qoi_obs_idx || !a->qoi_obs_w)) return bad("table pointer (null)");
+    for (int t = 0; t < nqz; ++t) if (a->qoi_obs_idx[t] < post_e0 || a->qoi_obs_idx[t] >= n) return bad("qoi_obs_idx (post nodes only)");
+    std::vector<int> fin_row(std::max(a->nfins, 1), -1);
+    for (int o = 0; o < d.n_obs; ++o) {
+      const int f = a->qoi_row_fin[o];
+      if (f < -1 || f >= a->nfins) return bad("qoi_row_fin");
+      if (f >= 0) { if (fin_row[f] >= 0) return bad("qoi_row_fin (a fin belongs to at most one row)"); fin_row[f] = o; }
+    }
+    for (int g = 0; g < a->npost; ++g) if (a->qoi_FgQ[post_g0 + g] != a->Fg[post_g0 + g]) return bad("qoi_FgQ (must equal Fg on the post)");
+    for (int f = 0; f < a->nfins; ++f)
+      if (fin_row[f] < 0)
+        for (int t = 0; t < ntot; ++t) if (a->qoi_FgQ[f * ntot + t] != 0.0) return bad("qoi_FgQ (weights on a fin no row owns)");
+    std::vector<double> full(n), rec(n);
+    for (int o = 0; o < d.n_obs; ++o) {
+      std::fill(full.begin(), full.end(), 0.0); std::fill(rec.begin(), rec.end(), 0.0);
+      for (int t = a->obs_ptr[o]; t < a->obs_ptr[o + 1]; ++t) full[a->obs_idx[t]] += a->obs_w[t];
+      for (int t = a->qoi_obs_ptr[o]; t < a->qoi_obs_ptr[o + 1]; ++t) rec[a->qoi_obs_idx[t]] += a->qoi_obs_w[t];
+      const int f = a->qoi_row_fin[o];
+      if (f >= 0) {
+        for (int t = 0; t < a->npf; ++t) rec[f * a->npf + t] += a->qoi_FgQ[f * ntot + t];
+        for (int t = 0; t < a->nif; ++t) rec[a->iface_elim[f * a->nif + t]] += a->qoi_FgQ[f * ntot + a->npf + t];
+      }
+      for (int i = 0; i < n; ++i) if (full[i] != rec[i]) return bad("QoI-only tables (not the operator obs_* describes)");
+    }
+  }
   if (gsize_out) *gsize_out = gsize;
   if (nL_out) *nL_out = nL;
   return 0;
@@ -607,6 +644,15 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (!rc) rc = up(h->owned, &b.obs_ptr, a->obs_ptr, d.n_obs + 1);
   if (!rc) rc = up(h->owned, &b.obs_idx, a->obs_idx, nobsnz);
   if (!rc) rc = up(h->owned, &b.obs_w, a->obs_w, nobsnz);
+  if (a->qoi_FgQ != nullptr && getenv("FINROM_BAND_NO_QOI_ONLY") == nullptr) {
+    const int nqz = a->qoi_obs_ptr[d.n_obs];
+    if (!rc) rc = up(h->owned, &b.FgQ, a->qoi_FgQ, G);
+    if (!rc) rc = up(h->owned, &b.row_fin, a->qoi_row_fin, d.n_obs);
+    if (!rc) rc = up(h->owned, &b.qobs_ptr, a->qoi_obs_ptr, d.n_obs + 1);
+    if (!rc) rc = up(h->owned, &b.qobs_idx, a->qoi_obs_idx, nqz);
+    if (!rc) rc = up(h->owned, &b.qobs_w, a->qoi_obs_w, nqz);
+    b.qo = 1;
+  }
   if (rc) return rc;
   b.on = getenv("FINROM_BAND_TIMING") != nullptr ? 2 : 1;      // 2: block 0 reports its phase clocks in sample 0's QoI (diagnostic)
   if (getenv("FINROM_BAND_NOMEM") != nullptr) b.on |= 4;       // timing experiment (m <= 12 kernel): no L / y / w traffic, garbage results

@@ -159,11 +159,16 @@ struct BandDev {
   const int* abmap;          // [3 G] physical value slot of each entry of a segment node
   const double* Fg; const int* act; const int* lx_ptr; const int* ent_extra; const int* ecp_ptr; const int* ecp_slot; const int* ecp_off;
   const int* schur_off; const int* iface_elim; const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
+  // QoI-only form (fom_band.hip): qo = its tables are installed
+  int qo = 0;
+  const double* FgQ = nullptr;       // [G] observation weights on the fins' segment nodes, the load on the post's
+  const int* qobs_ptr = nullptr; const int* qobs_idx = nullptr; const double* qobs_w = nullptr;   // post-only remainder of B_obs
+  const int* row_fin = nullptr;      // [n_obs] fin whose functional belongs to the row, -1: none
 };
 constexpr int BAND_LDS_XSIZE = 256;
 bool band_supported(int NSF, int NSP, int NX);
-int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st);
-int band_path(const BandDev& p);      // FINROM_FOM_PATH_* of the kernel launch_fom_band picks for these window sizes
+int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qoi_only);
+int band_path(const BandDev& p, bool qoi_only);      // FINROM_FOM_PATH_* of the kernel launch_fom_band picks
 
 // ---- learned error model (mlp_kernels.hip, finrom_mlp_*) ----------------------------------
 struct MlpDev {

@@ -70,7 +70,8 @@ struct PostTables {
 // ---- forward: factorisation fused with L y = F over one segment ----------------------------------------------------------
 // (PF: the right-hand side of the entering node travels with its three matrix entries -- for callers that run one wave per SIMD
 // or less, where nothing else hides the load; the m <= 12 kernel is HBM-bound and keeps its register budget)
-template <int NS, bool POST, int NXM, bool PF = false>
+// (NOSTORE, fins only: the QoI-only form below -- nothing of the segment's factor or y leaves the registers)
+template <int NS, bool POST, int NXM, bool PF = false, bool NOSTORE = false>
 __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, double* __restrict__ xs, const double* __restrict__ Fg,
                                            const int* __restrict__ abmap, const PostTables& T, int g0, int e0, int npiv, int ntot, int L0,
                                            double (&win)[NS * (NS + 1) / 2], double (&yw)[NS], int& bad) {
@@ -156,10 +157,12 @@ __device__ __forceinline__ void band_sweep(const BandDev& p, const Io& io, doubl
         double l[NS];
         static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; l[s_] = win[tri((u + s_) % NS, u)] * inv; });
         const int base = p.offL + L0 + pp * NS;
-        static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; io.template stk<s_ - 1>(l[s_], base); });
-        io.template stk<NS - 1>(inv, base);
+        if constexpr (!NOSTORE) {
+          static_for<1, NS>([&](auto sc) { constexpr int s_ = decltype(sc)::value; io.template stk<s_ - 1>(l[s_], base); });
+          io.template stk<NS - 1>(inv, base);
+        }
         const double yp = yw[u] * inv;
-        io.st(yp, p.offY + e0 + pp);
+        if constexpr (!NOSTORE) io.st(yp, p.offY + e0 + pp);
         static_for<1, NS>([&](auto sc) {
           constexpr int s_ = decltype(sc)::value;
           yw[(u + s_) % NS] = fma(-l[s_], yp, yw[(u + s_) % NS]);
@@ -767,7 +770,50 @@ __device__ __forceinline__ void band_bsweep(const BandDev& p, const Io& io, doub
   }
 }
 
-template <int NSF, int NSP, int NXM>
+// ---- QoI-only form (finrom_fom_solve / finrom_solve_pairs without w: the dataset loop, generate_fin_dataset.py:93-100) ------------
+// The observables are linear functionals of w, and a fin's own nodes I are leaves of the elimination: with its interface nodes
+// G on the post's side wall,   w_I = -A_II^-1 A_IG w_G   (the load is zero on the fins: checked when the plan is installed), so
+//     b_I^T w_I + b_G^T w_G = (b_G - A_GI A_II^-1 b_I)^T w_G =: g^T w_G .
+// g is what a forward sweep of the fin leaves in the right-hand-side window of its trailing (interface) nodes when the
+// observation row's weights b ride along AS the right-hand side -- which is free, since the true right-hand side is zero there.
+// The fin's columns of L, its y and its backward sweep are then never needed: 100 of the 266 KB per sample at m = 12 stay on
+// the chip.  g (nif doubles per fin) waits in the fin's unused y region for the post's backward sweep to deliver w_G.
+// Host side (engine.py::band_descriptor): FgQ = the observation weights on the fins' segment nodes and the load on the post's;
+// the post-only remainder of B_obs as CSR; row_fin[o] = the fin whose functional belongs to row o (-1: none).
+template <int NSF>
+__device__ __forceinline__ void fin_functional_out(const BandDev& p, const Io& io, const double (&yw)[NSF], int f, int npiv) {
+  for (int t = 0; t < p.nif; ++t) {
+    const int su = (npiv + t) % NSF;
+    double v = 0.0;
+    static_for<0, NSF>([&](auto uc) { constexpr int u = decltype(uc)::value; v = su == u ? yw[u] : v; });
+    io.st(v, p.offY + f * npiv + t);
+  }
+}
+// observable o from the post's w: the post-only part of the row + g^T w_G of the row's fin
+__device__ __forceinline__ double qoi_row(const BandDev& p, const Io& io, const int* __restrict__ obs_ptr, const int* __restrict__ obs_idx,
+                                          const double* __restrict__ obs_w, const int* __restrict__ row_fin,
+                                          const int* __restrict__ iface_elim, int o, bool qo) {
+  double q0 = 0.0, q1 = 0.0;
+  const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
+  for (int t = t0; t < t1; t += 8) {                     // loads batched by 8
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = io.ld(p.offY + obs_idx[(t + u < t1) ? t + u : t1 - 1]);
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      q0 = fma((t + u < t1) ? obs_w[t + u] : 0.0, v[u], q0);
+      q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
+    }
+  }
+  if (qo) {
+    const int f = row_fin[o];
+    if (f >= 0)
+      for (int t = 0; t < p.nif; ++t) q0 = fma(io.ld(p.offY + f * p.npf + t), io.ld(p.offY + iface_elim[f * p.nif + t]), q0);
+  }
+  return q0 + q1;
+}
+
+template <int NSF, int NSP, int NXM, bool QO>
 __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __restrict__ abmap, const double* __restrict__ Fg,
                                                       const int* __restrict__ act,
                                                       const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra,
@@ -775,6 +821,7 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __re
                                                       const int* __restrict__ ecp_off, const int* __restrict__ schur_off,
                                                       const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr,
                                                       const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                      const int* __restrict__ row_fin,
                                                       double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,
                                                       int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double xlds[];
@@ -792,7 +839,8 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __re
     double win[NSF * (NSF + 1) / 2], yw[NSF];
     for (int f = 0; f < p.nfins; ++f) {
       const int npiv = p.npf, ntot = p.npf + p.nif;
-      band_sweep<NSF, false, NXM>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      band_sweep<NSF, false, NXM, false, QO>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      if constexpr (QO) fin_functional_out<NSF>(p, io, yw, f, npiv);
       // what is left in the window is the fin's Schur complement on its interface nodes: add it to their entries in the post
       int k = 0;
       for (int t = 0; t < p.nif; ++t)
@@ -815,29 +863,19 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __re
     band_sweep<NSP, true, NXM>(p, io, xs, Fg, abmap, T, p.post_g0, p.post_e0, p.npost, p.npost, p.post_L0, win, yw, bad);
   }
   band_bsweep<NSP, true, NXM>(p, io, xs, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0);
-  for (int f = 0; f < p.nfins; ++f)
-    band_bsweep<NSF, false, NXM>(p, io, xs, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF);
+  if constexpr (!QO)
+    for (int f = 0; f < p.nfins; ++f)
+      band_bsweep<NSF, false, NXM>(p, io, xs, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF);
 
   const int64_t s = blk * 64 + lane;
   const double nanv = __builtin_nan("");
   if (bad) {                                             // not positive definite: NaN outputs and the flag, as the interpreter does
-    for (int i = 0; i < p.n; ++i) io.st(nanv, p.offY + i);
+    if constexpr (!QO) for (int i = 0; i < p.n; ++i) io.st(nanv, p.offY + i);
     if (info != nullptr && s < S) atomicOr(&info[s], 1);
   }
-  for (int o = 0; o < p.n_obs; ++o) {                    // QoI = B_obs w (fom :408-412), loads batched by 8
-    double q0 = 0.0, q1 = 0.0;
-    const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
-    for (int t = t0; t < t1; t += 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = io.ld(p.offY + obs_idx[(t + u < t1) ? t + u : t1 - 1]);
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) {
-        q0 = fma((t + u < t1) ? obs_w[t + u] : 0.0, v[u], q0);
-        q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
-      }
-    }
-    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q0 + q1;
+  for (int o = 0; o < p.n_obs; ++o) {                    // QoI = B_obs w (fom :408-412)
+    const double q = qoi_row(p, io, obs_ptr, obs_idx, obs_w, row_fin, iface_elim, o, QO);
+    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q;
   }
 }
 
@@ -850,6 +888,7 @@ __global__ __launch_bounds__(64) void fom_band_lds_kernel(BandDev p, const int* 
                                                           const int* __restrict__ ecp_off, const int* __restrict__ schur_off,
                                                           const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr,
                                                           const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                          const int* __restrict__ /*row_fin*/,
                                                           double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,
                                                           int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double xlds[];
@@ -1036,7 +1075,7 @@ __device__ __forceinline__ void band_bsweep_ldsw(const BandDev& p, const Io& io,
 
 // WV waves per 64 samples: the eight fins are independent (shared over the waves), the post's forward sweep is band_sweep_ldsr,
 // its backward sweep runs on wave 0 with a deeper column ring
-template <int NSF, int NSP, int NXM, int WV>
+template <int NSF, int NSP, int NXM, int WV, bool QO>
 __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* __restrict__ abmap, const double* __restrict__ Fg,
                                                               const int* __restrict__ act,
                                                               const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra,
@@ -1044,6 +1083,7 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
                                                               const int* __restrict__ ecp_off, const int* __restrict__ schur_off,
                                                               const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr,
                                                               const int* __restrict__ obs_idx, const double* __restrict__ obs_w,
+                                                              const int* __restrict__ row_fin,
                                                               double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,
                                                               int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) double xlds[];
@@ -1062,7 +1102,8 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
     double win[NSF * (NSF + 1) / 2], yw[NSF];
     for (int f = wv; f < p.nfins; f += WV) {
       const int npiv = p.npf, ntot = p.npf + p.nif;
-      band_sweep<NSF, false, NXM, true>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      band_sweep<NSF, false, NXM, true, QO>(p, io, xs, Fg, abmap, T, f * ntot, f * npiv, npiv, ntot, f * npiv * NSF, win, yw, bad);
+      if constexpr (QO) fin_functional_out<NSF>(p, io, yw, f, npiv);
       int k = 0;
       for (int t = 0; t < p.nif; ++t)
         for (int s = 0; s <= t; ++s, ++k) {
@@ -1097,8 +1138,9 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
   }
   __syncthreads();
   tk[3] = wall_clock64();
-  for (int f = wv; f < p.nfins; f += WV)
-    band_bsweep<NSF, false, NXM>(p, io, xs, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF);
+  if constexpr (!QO)
+    for (int f = wv; f < p.nfins; f += WV)
+      band_bsweep<NSF, false, NXM>(p, io, xs, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF);
   xs[FLAG * 64] = 0.0;
   __syncthreads();
   if (bad) xs[FLAG * 64] = 1.0;                          // a fin's wave may be the only one that saw its failure
@@ -1109,23 +1151,14 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
   const int64_t s = blk * 64 + lane;
   const double nanv = __builtin_nan("");
   if (bad) {
-    for (int i = wv; i < p.n; i += WV) io.st(nanv, p.offY + i);
+    if constexpr (!QO) for (int i = wv; i < p.n; i += WV) io.st(nanv, p.offY + i);
     if (wv == 0 && info != nullptr && s < S) atomicOr(&info[s], 1);
   }
+  // (QO: the fins' functionals were written by whichever wave swept the fin -- before the __syncthreads() above -- and w of
+  // the post by wave 0: same CU, same L1)
   for (int o = wv; o < p.n_obs; o += WV) {
-    double q0 = 0.0, q1 = 0.0;
-    const int t0 = obs_ptr[o], t1 = obs_ptr[o + 1];
-    for (int t = t0; t < t1; t += 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = io.ld(p.offY + obs_idx[(t + u < t1) ? t + u : t1 - 1]);
-#pragma unroll
-      for (int u = 0; u < 8; u += 2) {
-        q0 = fma((t + u < t1) ? obs_w[t + u] : 0.0, v[u], q0);
-        q1 = fma((t + u + 1 < t1) ? obs_w[t + u + 1] : 0.0, v[u + 1], q1);
-      }
-    }
-    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q0 + q1;
+    const double q = qoi_row(p, io, obs_ptr, obs_idx, obs_w, row_fin, iface_elim, o, QO);
+    if (s < S) qoi[s * p.n_obs + o] = bad ? nanv : q;
   }
   if ((p.on & 2) && s == 0 && wv == 0) {                 // FINROM_BAND_TIMING: 100 MHz ticks per phase (after everybody's QoI)
     __builtin_amdgcn_s_sleep(127);
@@ -1136,13 +1169,17 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
 #define FR_BAND_ARGS BandDev p, const int* __restrict__ abmap, const double* __restrict__ Fg, const int* __restrict__ act,                  \
     const int* __restrict__ lx_ptr, const int* __restrict__ ent_extra, const int* __restrict__ ecp_ptr, const int* __restrict__ ecp_slot,  \
     const int* __restrict__ ecp_off, const int* __restrict__ schur_off, const int* __restrict__ iface_elim, const int* __restrict__ obs_ptr, \
-    const int* __restrict__ obs_idx, const double* __restrict__ obs_w, double* __restrict__ Gw, int64_t S, double* __restrict__ qoi,       \
-    int* __restrict__ info
-#define FR_BAND_PASS p, abmap, Fg, act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off, schur_off, iface_elim, obs_ptr, obs_idx, obs_w, Gw, S, qoi, info
-template <int NSF, int NSP, int NXM, int WV>
-__global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(FR_BAND_ARGS) { fom_band_ldsw_body<NSF, NSP, NXM, WV>(FR_BAND_PASS); }
+    const int* __restrict__ obs_idx, const double* __restrict__ obs_w, const int* __restrict__ row_fin, double* __restrict__ Gw, int64_t S, \
+    double* __restrict__ qoi, int* __restrict__ info
+#define FR_BAND_PASS p, abmap, Fg, act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off, schur_off, iface_elim, obs_ptr, obs_idx, obs_w, row_fin, Gw, S, qoi, info
+template <int NSF, int NSP, int NXM, int WV, bool QO>
+__global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(FR_BAND_ARGS) { fom_band_ldsw_body<NSF, NSP, NXM, WV, QO>(FR_BAND_PASS); }
 
-template <int NSF, int NSP, int NXM = 8>
+// kernel arguments of one launch: the QoI-only form reads the combined table FgQ for Fg and the post-only rows for B_obs
+#define FR_BAND_LAUNCH_ARGS(qo) p, p.abmap, (qo) ? p.FgQ : p.Fg, p.act, p.lx_ptr, p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, \
+    p.iface_elim, (qo) ? p.qobs_ptr : p.obs_ptr, (qo) ? p.qobs_idx : p.obs_idx, (qo) ? p.qobs_w : p.obs_w, p.row_fin, Gw, S, qoi, info
+
+template <int NSF, int NSP, bool QO, int NXM = 8>
 int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int WV = 4;
   static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
@@ -1152,11 +1189,9 @@ int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* q
   static_assert(lds <= 160 * 1024, "LDS window");
   static PerDeviceOnce once;
   if (int rc = once.run([&]() -> int {
-        FR_HIP(hipFuncSetAttribute((const void*)fom_band_ldsw_kernel<NSF, NSP, NXM, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FR_HIP(hipFuncSetAttribute((const void*)fom_band_ldsw_kernel<NSF, NSP, NXM, WV, QO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         return 0; })) return rc;
-  hipLaunchKernelGGL((fom_band_ldsw_kernel<NSF, NSP, NXM, WV>), dim3((unsigned)nblk), dim3(64 * WV), lds, st, p, p.abmap, p.Fg, p.act,
-                     p.lx_ptr, p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx,
-                     p.obs_w, Gw, S, qoi, info);
+  hipLaunchKernelGGL((fom_band_ldsw_kernel<NSF, NSP, NXM, WV, QO>), dim3((unsigned)nblk), dim3(64 * WV), lds, st, FR_BAND_LAUNCH_ARGS(QO));
   FR_HIP(hipGetLastError());
   return 0;
 }
@@ -1173,20 +1208,16 @@ int launch_lds(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qo
   if (int rc = once.run([&]() -> int {
         FR_HIP(hipFuncSetAttribute((const void*)fom_band_lds_kernel<NSF, NSP, NXM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         return 0; })) return rc;
-  hipLaunchKernelGGL((fom_band_lds_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.abmap, p.Fg, p.act, p.lx_ptr,
-                     p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx, p.obs_w,
-                     Gw, S, qoi, info);
+  hipLaunchKernelGGL((fom_band_lds_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, FR_BAND_LAUNCH_ARGS(false));
   FR_HIP(hipGetLastError());
   return 0;
 }
 
-template <int NSF, int NSP>
+template <int NSF, int NSP, bool QO>
 int launch_t(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int NXM = 4;
   const size_t lds = (size_t)XL<NSP, NXM>::SIZE * 64 * sizeof(double);
-  hipLaunchKernelGGL((fom_band_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.abmap, p.Fg, p.act, p.lx_ptr,
-                     p.ent_extra, p.ecp_ptr, p.ecp_slot, p.ecp_off, p.schur_off, p.iface_elim, p.obs_ptr, p.obs_idx, p.obs_w,
-                     Gw, S, qoi, info);
+  hipLaunchKernelGGL((fom_band_kernel<NSF, NSP, NXM, QO>), dim3((unsigned)nblk), dim3(64), lds, st, FR_BAND_LAUNCH_ARGS(QO));
   FR_HIP(hipGetLastError());
   return 0;
 }
@@ -1207,24 +1238,29 @@ static bool band_one_wave_lds() {
 #endif
 }
 
-int band_path(const BandDev& p) {
-  if (p.NSP <= 14) return FINROM_FOM_PATH_BAND_REGISTERS;
-  return band_one_wave_lds() ? FINROM_FOM_PATH_BAND_LDS_1WAVE : FINROM_FOM_PATH_BAND_LDS_4WAVE;
+int band_path(const BandDev& p, bool qoi_only) {
+  const bool qo = qoi_only && p.qo;
+  if (p.NSP <= 14) return qo ? FINROM_FOM_PATH_BAND_REGISTERS_QOI : FINROM_FOM_PATH_BAND_REGISTERS;
+  if (band_one_wave_lds()) return FINROM_FOM_PATH_BAND_LDS_1WAVE;
+  return qo ? FINROM_FOM_PATH_BAND_LDS_4WAVE_QOI : FINROM_FOM_PATH_BAND_LDS_4WAVE;
 }
 
-int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
+// qoi_only: the caller wants no w; with the plan's QoI-only tables installed (BandDev::qo) the fins then ride as functionals
+int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qoi_only) {
   if (nblk == 0) return 0;
   ScopedKernelTimer t(p.NSP <= 14 ? K_FOM_PATH_BAND_REG : K_FOM_PATH_BAND_LDSW, st);
-  if (p.NSF == 3 && p.NSP == 6) return launch_t<3, 6>(p, Gw, nblk, S, qoi, info, st);
-  if (p.NSF == 4 && p.NSP == 10) return launch_t<4, 10>(p, Gw, nblk, S, qoi, info, st);
-  if (p.NSF == 5 && p.NSP == 14) return launch_t<5, 14>(p, Gw, nblk, S, qoi, info, st);
+  const bool qo = qoi_only && p.qo;
+#define FR_T(A, B) if (p.NSF == A && p.NSP == B) return qo ? launch_t<A, B, true>(p, Gw, nblk, S, qoi, info, st) : launch_t<A, B, false>(p, Gw, nblk, S, qoi, info, st);
+  FR_T(3, 6) FR_T(4, 10) FR_T(5, 14)
+#undef FR_T
 #ifdef FINROM_BUILD_ONE_WAVE_LDS      // A/B: the single-wave LDS sweep (a minute of compile time; -DFINROM_BUILD_ONE_WAVE_LDS + FINROM_BAND_LDS_ONE_WAVE=1)
   const bool one_wave = band_one_wave_lds();
   if (one_wave && p.NSF == 6 && p.NSP == 18) return launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st);
   if (one_wave && p.NSF == 7 && p.NSP == 22) return launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st);
 #endif
-  if (p.NSF == 6 && p.NSP == 18) return launch_ldsw<6, 18>(p, Gw, nblk, S, qoi, info, st);
-  if (p.NSF == 7 && p.NSP == 22) return launch_ldsw<7, 22>(p, Gw, nblk, S, qoi, info, st);
+#define FR_W4(A, B) if (p.NSF == A && p.NSP == B) return qo ? launch_ldsw<A, B, true>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<A, B, false>(p, Gw, nblk, S, qoi, info, st);
+  FR_W4(6, 18) FR_W4(7, 22)
+#undef FR_W4
   set_error("fom band sweep: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }

@@ -170,6 +170,7 @@ class FomEngine:
         optr, oidx, ow = _csr_rows(Bp)
         nif = bp.q + 1
         schur = np.asarray([[abmap[off] for _, _, off in tg] for tg in bp.schur_target], np.int32)
+        qo = FomEngine.qoi_only_tables(bp, Bp, Fg)
         keep = []
 
         def I(a):
@@ -183,7 +184,51 @@ class FomEngine:
                         ecp_ptr=I(bp.ecp_ptr), ecp_slot=I(bp.ecp_slot), ecp_off=I(abmap[bp.ecp_off] if len(bp.ecp_off) else bp.ecp_off),
                         schur_off=I(schur), iface_elim=I(bp.iface_elim), perm=I(bp.perm),
                         obs_ptr=I(optr), obs_idx=I(oidx), obs_w=D(ow))
+        if qo is not None:
+            FgQ, row_fin, qptr, qidx, qw = qo
+            d.qoi_FgQ, d.qoi_row_fin, d.qoi_obs_ptr, d.qoi_obs_idx, d.qoi_obs_w = D(FgQ), I(row_fin), I(qptr), I(qidx), D(qw)
         return d, keep, len(c0p)
+
+    @staticmethod
+    def qoi_only_tables(bp, Bp, Fg):
+        """Tables of the band sweep's QoI-only form (include/finrom.h, finrom_fom_band_desc::qoi_*): every observation row is
+        split into the weights on ONE fin's segment nodes (own + interface: they ride through that fin's forward sweep as its
+        right-hand side) and a post-only remainder.  None when the observation operator does not split that way (a row with
+        weights on the own nodes of two fins, two rows on one fin -- e.g. the 40 point observations of external_obs -- or a load
+        on the fins): the full sweep then serves every call."""
+        Bp = sp.csr_matrix(Bp)
+        n_obs = Bp.shape[0]
+        npf, nfins, nif = bp.npf, bp.nfins, bp.q + 1
+        ntot, post_e0 = npf + nif, nfins * npf
+        if np.any(Fg[:nfins * ntot] != 0.0):
+            return None
+        row_fin = np.full(n_obs, -1, np.int32)
+        fin_row = np.full(nfins, -1, np.int64)
+        for o in range(n_obs):
+            idx = Bp.indices[Bp.indptr[o]:Bp.indptr[o + 1]]
+            fins = np.unique(idx[idx < post_e0] // npf)
+            if len(fins) > 1:
+                return None
+            if len(fins) == 1:
+                if fin_row[fins[0]] >= 0:
+                    return None
+                row_fin[o], fin_row[fins[0]] = fins[0], o
+        FgQ = np.array(Fg, dtype=np.float64, copy=True)
+        qptr, qidx, qw = [0], [], []
+        for o in range(n_obs):
+            idx = Bp.indices[Bp.indptr[o]:Bp.indptr[o + 1]]; val = Bp.data[Bp.indptr[o]:Bp.indptr[o + 1]]
+            f = int(row_fin[o])
+            iface = {int(e): t for t, e in enumerate(bp.iface_elim[f])} if f >= 0 else {}
+            for e, v in zip(idx, val):
+                e = int(e)
+                if e < post_e0:
+                    FgQ[f * ntot + (e - f * npf)] = v
+                elif e in iface:
+                    FgQ[f * ntot + npf + iface[e]] = v
+                else:
+                    qidx.append(e); qw.append(v)
+            qptr.append(len(qidx))
+        return FgQ, row_fin, np.asarray(qptr, np.int32), np.asarray(qidx, np.int32), np.asarray(qw, np.float64)
 
     def _enable_band(self, ops, c0_csr, W_csr, rhs, B_obs):
         """Install the frontal band sweep (finrom_fom_set_band) when the mesh has a band plan and the library was built with
@@ -198,6 +243,7 @@ class FomEngine:
         check(rc, "finrom_fom_set_band")
         self.band = bp
         self.band_slots = nslots            # physical value slots per sample (bench: algorithmic bytes)
+        self.band_qoi_only = bool(d.qoi_FgQ) and _os.environ.get("FINROM_BAND_NO_QOI_ONLY") is None      # calls without w: QoI-only form
 
     def solve(self, X, want_w=False):
         b = _Batch(X, self.xdim)

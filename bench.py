@@ -566,6 +566,11 @@ def roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl)
             # frontal band sweep: value slots read once, every column of L (+ extras) written once and read once, y written and
             # read, w written, QoI out -- nothing else leaves the registers
             # (value slots: the physical ones -- slots with the same affine record are shared and mostly served by L2)
+            if getattr(eng, "band_qoi_only", False):
+                # QoI-only form (the pair path asks for no w): only the POST's columns, y and w travel; a fin leaves nif doubles
+                nLp = bp.npost * bp.NSP
+                return hbm(8 * (eng.band_slots + 2 * nLp + 2 * bp.nLx + 3 * bp.npost + 2 * bp.nfins * (bp.q + 1) + n_obs),
+                           "QoI-only form: value slots + 2 (L_post + Lx) + 3 n_post + 2 nfins nif + n_obs doubles per sample")
             return hbm(8 * (eng.band_slots + 2 * bp.nL + 2 * bp.nLx + 3 * n + n_obs), "value slots + 2 (L + Lx) + 3 n + n_obs doubles per sample")
         # interpreter: lower bound -- L written once and read once, y / w, parameters; its operand re-fetches come on top
         return hbm(8 * (2 * plan.nnzL + 4 * n + pairs.xdim + n_obs), "lower bound: 2 nnz(L) + 4 n + xdim + n_obs doubles per sample")

@@ -193,8 +193,10 @@ int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* desc);
  * Couplings longer than B make the far node an *extra* of the post sweep: act[p] = bit mask of extra slots that pivot p
  * updates (their L values are stored at lx_ptr[p]..), ent_extra[p] = slot + 1 if node p was an extra before it entered the
  * window, (ecp_slot, ecp_off) in [ecp_ptr[p], ecp_ptr[p+1]) = couplings AB[off] of node p to extras, set when p enters.
- * Supported windows: (NSF, NSP) = (3, 6), (4, 10), (5, 14) (m = 4, 8, 12), NX <= 4; otherwise FINROM_ERR_UNSUPPORTED and
- * the handle keeps using the interpreter.  finrom_fom_gradient always uses the interpreter's stored factor. */
+ * Supported windows: (NSF, NSP) = (3, 6), (4, 10), (5, 14) (m = 4, 8, 12; window in registers), NX <= 4, and (6, 18), (7, 22)
+ * (m = 16, 20; the post's window over four waves), NX <= 8; otherwise FINROM_ERR_UNSUPPORTED and the handle keeps using the
+ * interpreter -- as it does when the load Fg is not zero on the fins' own nodes (the sweep does not carry a fin's load to its
+ * interface).  finrom_fom_gradient always uses the interpreter's stored factor. */
 typedef struct {
   int32_t NSF, NSP, NX;      /* window slots of a fin sweep / of the post sweep, extra slots */
   int32_t nfins, npf, nif;   /* fins, pivots per fin, interface nodes per fin */
@@ -210,6 +212,16 @@ typedef struct {
   const int32_t* iface_elim; /* [nfins][nif] elimination index of each interface node */
   const int32_t* perm;       /* [n] elimination index -> dof */
   const int32_t* obs_ptr; const int32_t* obs_idx; const double* obs_w;      /* B_obs (CSR) over elimination indices */
+  /* Optional (all five or none): the QoI-only form, used when a solve asks for no w (the dataset loop keeps only the
+   * observables, generate_fin_dataset.py:93-100).  A fin's own nodes are leaves of the elimination and carry no load, so an
+   * observation row's weights on them can ride through the fin's forward sweep as its right-hand side and leave a functional of
+   * the fin's interface values; the fin's factor, y and backward sweep are then never stored or run (csrc/fom_band.hip).
+   *   qoi_FgQ [as Fg]   the weights of the fin's row on the fin's segment nodes (own, then interface), Fg on the post's;
+   *   qoi_row_fin [n_obs]  the fin whose functional belongs to row o, or -1; a fin belongs to at most one row;
+   *   qoi_obs_*         CSR of what remains of B_obs: post nodes only, without the row's own fin's interface nodes.
+   * Checked on the host against obs_*: both descriptions must be the same operator, entry by entry. */
+  const double* qoi_FgQ; const int32_t* qoi_row_fin;
+  const int32_t* qoi_obs_ptr; const int32_t* qoi_obs_idx; const double* qoi_obs_w;
 } finrom_fom_band_desc;
 int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* desc);
 /* The checks finrom_fom_set_band applies before it touches the device, for a FOM of n dofs, xdim parameters and n_obs
@@ -232,6 +244,8 @@ int finrom_fom_band_validate(const finrom_fom_band_desc* desc, int32_t n, int32_
 #define FINROM_FOM_PATH_BAND_REGISTERS 4   /* fom_band_kernel: frontal band sweep, front in registers (m <= 12) */
 #define FINROM_FOM_PATH_BAND_LDS_4WAVE 5   /* fom_band_ldsw_kernel: post's window over four waves + LDS exchange (m = 16, 20) */
 #define FINROM_FOM_PATH_BAND_LDS_1WAVE 6   /* fom_band_lds_kernel: one-wave LDS window (A/B builds only) */
+#define FINROM_FOM_PATH_BAND_REGISTERS_QOI 7   /* fom_band_kernel, QoI-only form: fins ride as functionals, no w */
+#define FINROM_FOM_PATH_BAND_LDS_4WAVE_QOI 8   /* fom_band_ldsw_kernel, QoI-only form */
 int finrom_fom_last_path(finrom_fom_t h);
 int finrom_fom_set_small_max(finrom_fom_t h, int32_t small_max);
 

@@ -1,7 +1,8 @@
 """The frontal band sweep (csrc/fom_band.hip) against the oracle and against the schedule interpreter it replaces on the
 throughput path: w and QoI <= 1e-10 relative for nodal fields and for five / nine fin conductivities, on every mesh the library
 has window sizes for -- the front in registers (m = 4, 8, 12: fom_band_kernel) and the post's window over four waves with LDS as
-the exchange (m = 16, 20: fom_band_ldsw_kernel) -- failure flags for indefinite operators, batch tails.
+the exchange (m = 16, 20: fom_band_ldsw_kernel), each in its full form (w wanted) and in its QoI-only form -- failure flags for
+indefinite operators, batch tails.
 
 Every case ASSERTS WHICH KERNEL RAN (finrom_fom_last_path): the small-batch schedule takes batches of <= 512 samples (<= 4096
 when the value vector does not fit LDS, i.e. m >= 16), so a test that only sizes its batch "large" can silently compare
@@ -67,10 +68,15 @@ def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
             assert np.linalg.norm(res["w"][s] - w) < TOL * np.linalg.norm(w), (params, s)
             q = fo.qoi_operator(w)
             assert np.linalg.norm(res["qoi"][s] - q) < TOL * np.linalg.norm(q), (params, s)
-        # QoI-only calls (the sample-pair path asks for no w) take the same kernel and give the same observables
+        # QoI-only calls (the sample-pair path asks for no w) take the kernel's QoI-only form: the fins ride through their
+        # forward sweeps as functionals of the interface values -- no factor, y or backward sweep for them (fom_band.hip)
         res_q = fin.forward_batch(X, want_w=False, params=kw["params"])
-        assert fin._engine(params).last_path() == BAND_PATH[m]
-        assert np.array_equal(res_q["qoi"], res["qoi"])
+        assert fin._engine(params).last_path() == BAND_PATH[m] + "_qoi"
+        assert (res_q["info"] == 0).all()
+        assert _rel(res_q["qoi"], res["qoi"]) < 1e-11
+        for s in picks:
+            q = fo.qoi_operator(fo.forward(lift(X[s])))
+            assert np.linalg.norm(res_q["qoi"][s] - q) < TOL * np.linalg.norm(q), (params, s, "qoi-only")
 
 
 @pytest.mark.parametrize("m", [12, 16, 20])
@@ -91,6 +97,12 @@ def test_band_sweep_flags_indefinite_samples(spaces, m):
         assert np.isnan(res["qoi"][s]).all() and np.isnan(res["w"][s]).all()
     good = np.setdiff1d(np.arange(600), bad)
     assert np.isfinite(res["qoi"][good]).all() and np.isfinite(res["w"][good]).all()
+    # the same through the QoI-only form
+    res_q = fin.forward_batch(X, want_w=False, params="nine")
+    assert fin._engine("nine").last_path() == BAND_PATH[m] + "_qoi"
+    assert np.nonzero(res_q["info"])[0].tolist() == bad
+    assert np.isnan(res_q["qoi"][bad]).all() and np.isfinite(res_q["qoi"][good]).all()
+    assert _rel(res_q["qoi"][good], res["qoi"][good]) < 1e-11
 
 
 @pytest.mark.parametrize("m,small_path,small_max", [(12, "small_lds", 512), (20, "small_global", 4096)])
@@ -105,7 +117,7 @@ def test_dispatch_by_batch_size(spaces, m, small_path, small_max):
     a = fin.forward_batch(X[:small_max], want_w=False, params="nine")
     assert eng.last_path() == small_path
     b = fin.forward_batch(X, want_w=False, params="nine")
-    assert eng.last_path() == BAND_PATH[m]
+    assert eng.last_path() == BAND_PATH[m] + "_qoi"
     # two schedules of the same factorisation (other elimination order, other summation order): round-off times the operator's
     # condition number (kappa in [0.1, 10]: 2e-12 measured at m = 20), an order below the parity tolerance
     assert _rel(a["qoi"], b["qoi"][:small_max]) < 1e-11

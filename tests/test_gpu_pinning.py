@@ -30,7 +30,7 @@ def test_fom_observables_converge_at_the_p1_rate(problems, spaces):
         fin = Fin(spaces(m))
         fin._engine("nine").set_small_max(0)                 # the throughput path whatever the batch size (asserted below)
         res = fin.forward_batch(np.tile(kappa, (600, 1)), want_w=False, params="nine")
-        assert fin._engine("nine").last_path() == ("band_lds_4wave" if m == 16 else "band_registers")
+        assert fin._engine("nine").last_path() == ("band_lds_4wave_qoi" if m == 16 else "band_registers_qoi")
         assert (res["info"] == 0).all()
         q_gpu[m] = res["qoi"][17]
         assert np.linalg.norm(q_gpu[m] - q_or[m]) < 1e-10 * np.linalg.norm(q_or[m])

@@ -128,7 +128,7 @@ def band_cases(m, kinds, corrupt):
         # a logical value slot de-duplicated onto a slot a fin writes to would be a second reader of that slot
         tweak(d.abmap, 0, d.schur_off[0], call, "band: a Schur slot is also somebody's plain value slot")
         for field in ("abmap", "ab_ptr", "ab_c0", "Fg", "act", "lx_ptr", "ent_extra", "ecp_ptr", "ecp_off", "schur_off", "iface_elim",
-                      "perm", "obs_ptr", "obs_idx"):
+                      "perm", "obs_ptr", "obs_idx", "qoi_FgQ", "qoi_obs_ptr"):
             ptype = type(getattr(d, field))
             addr = C.cast(getattr(d, field), C.c_void_p).value      # (the attribute is a VIEW of the field: keep the address)
             setattr(d, field, ptype())                  # NULL pointer
@@ -136,6 +136,18 @@ def band_cases(m, kinds, corrupt):
                 expect_error(f"band: {field} is NULL", call())
             finally:
                 setattr(d, field, C.cast(addr, ptype))
+        # the QoI-only tables must describe the same operator as obs_*
+        assert bool(d.qoi_FgQ) and bool(d.qoi_row_fin), "QoI-only tables missing for the sub-fin averages"
+        o_fin = next(o for o in range(fin.n_obs) if d.qoi_row_fin[o] >= 0)
+        f_ = d.qoi_row_fin[o_fin]
+        tweak(d.qoi_FgQ, f_ * (d.npf + d.nif) + 3, 0.125, call, "band: QoI-only weight differs from B_obs")
+        tweak(d.qoi_FgQ, bp.G - 1, d.Fg[bp.G - 1] + 1.0, call, "band: QoI-only load differs from Fg on the post")
+        tweak(d.qoi_row_fin, o_fin, -1, call, "band: a row lost its fin")
+        o_post = next(o for o in range(fin.n_obs) if d.qoi_row_fin[o] < 0)
+        tweak(d.qoi_row_fin, o_post, f_, call, "band: two rows claim one fin")
+        tweak(d.qoi_obs_idx, 0, 0, call, "band: QoI-only remainder points into a fin")
+        tweak(d.qoi_obs_w, 0, d.qoi_obs_w[0] * 2, call, "band: QoI-only remainder weight differs")
+        tweak(d.Fg, 5, 1.0, call, "band: load on a fin node")
         for field, val in (("npf", d.NSF - 1), ("npost", d.NSP - 1), ("nif", d.nif + 1), ("NSP", 15), ("nAB", 0)):
             old = getattr(d, field); setattr(d, field, val)
             try:
