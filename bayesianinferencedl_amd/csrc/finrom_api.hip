@@ -1208,7 +1208,13 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   // every sweep wave, and since the projection hides its non-MFMA work behind its own MFMAs a lone wave per SIMD is efficient:
   // measured 26.3 ms side by side against 29.1 ms in turn per 100k samples (r = 80).
   static const bool env_no_overlap = getenv("FINROM_NO_OVERLAP") != nullptr;      // (read once, not per call)
-  const bool overlap = g_overlap && !env_no_overlap;
+  static const bool env_force_overlap = getenv("FINROM_FORCE_OVERLAP") != nullptr;
+  // The four-wave band sweep (m = 16, 20) takes a whole CU's LDS (157 KB per workgroup) and the wide-basis projection 43 KB per
+  // workgroup: the two kernels cannot share a CU, side by side they only took turns at the hardware's discretion (r = 200, 125k
+  // samples: step 420 ms against 428 in turn, the sweep event-timed at 203 ms instead of its 21 ms, the sub-fin averages starved
+  // ninefold).  Those sizes run in turn -- same throughput, meaningful kernel timings; FINROM_FORCE_OVERLAP=1 for A/B.
+  const bool lds_exclusive = fom->band.on && fom->band.NSP > 14 && !env_force_overlap;
+  const bool overlap = g_overlap && !env_no_overlap && !lds_exclusive;
   hipStream_t side = overlap ? rom->side : st;
   const bool tracing = trace_prefix() != nullptr;
   if (tracing) {
@@ -1220,11 +1226,7 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     fom->d.trace = (size_t)((S + 63) / 64) <= kTraceWg ? g_trace_buf[0] : nullptr;
     rom->d.trace = (size_t)S <= kTraceWg ? g_trace_buf[1] : nullptr;
   }
-  // fork: everything already queued on the caller's stream (inputs, zeroed info) precedes both halves
-  if (overlap) {
-    FR_HIP(hipEventRecord(rom->ev_fork, st));
-    FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
-  }
+  // (the fork below: everything already queued on the caller's stream -- inputs, zeroed info -- precedes both halves)
   // ROM half first, on a high-priority stream: its 4-wave, 160-VGPR workgroups need large contiguous
   // register ranges, so they claim their slots before the small FOM waves fill the remaining ones
   // The FOM's short bandwidth-bound pre-pass (pack + assembly) runs first, alone; beside the projection kernel it
@@ -1237,11 +1239,13 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   };
   auto fail = [&](int code) { if (overlap) (void)hipStreamSynchronize(side); return code; };
   if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return rc;          // (reserves the FOM workspace)
-  if (overlap && split) {                 // the ROM half starts after the pre-pass
+  // the sub-fin averages (bandwidth-bound, short) run BEFORE the fork, alone: beside the sweep they were starved (0.19 -> 0.39 ms
+  // at the headline, 0.6 -> 5.8 ms at m = 20) and they head the ROM half's critical path
+  if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, st))) return fail(rc);
+  if (overlap) {                          // the ROM half starts after the pre-pass and the averages
     FR_HIP(hipEventRecord(rom->ev_fork, st));
     FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
   }
-  if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, side))) return fail(rc);
   if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return fail(rc);
   if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, split ? 2 : 3))) return fail(rc);
   join();
