@@ -848,10 +848,6 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 
   // let the last MFMAs retire before their results are read (no hazard padding around inline asm)
   mfma_drain(acc);
-  // FINROM_CLOCK_PROBE=7 (split-K kernel, sample 0): phase clocks of the one-sample call, 10 ns ticks
-  long long pk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool probe = SK && p.clock_probe == 7 && s == 0;
-  if (probe) pk[0] = __builtin_amdgcn_s_memrealtime();
   if constexpr (NW == 1) {
     if (kparts > 1) {
       if (kpart > 0) {
@@ -869,7 +865,6 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
           for (int g = 0; g < 4; ++g) acc[t][g] += slab[((w - 1) * NTL + t) * 256 + g * 64 + lane];
     }
   }
-  if (probe) pk[1] = __builtin_amdgcn_s_memrealtime();
   int bad = 0;
   // factor == 2 with nothing but qoi_r wanted (the sample-pair path): factorisation, both substitutions and the reduced QoI as
   // MFMA-form panel operations (fused_solve_sw), after B_r below
@@ -881,7 +876,6 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
       if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
     }
   }
-  if (probe) pk[2] = __builtin_amdgcn_s_memrealtime();
   // factor == 2: substitutions + QoI below, nothing stored but w_r, qoi_r (r <= 80)
   // factor == 3 (multi-wave kernels): factorisation + QoI in registers, nothing stored but qoi_r (fused_solve_mw)
   // factor == 4 (split-K kernel, SK): also the adjoint solve; v_r, w_r go to RomGradArgs::vw for rom_grad_contract_small_kernel
@@ -952,9 +946,7 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     if constexpr (NW == 1 && (NB <= 5 || SK)) {
       if (fused_solve) {
         double xr[NB];
-        if (probe) pk[3] = __builtin_amdgcn_s_memrealtime();
         solve_tiles<NB>(acc, bacc, q, c, xr);
-        if (probe) pk[4] = __builtin_amdgcn_s_memrealtime();
         const double nanv = __builtin_nan("");
         if constexpr (SK) {
           if (factor == 4) {
@@ -993,9 +985,7 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 #pragma unroll
             for (int t = 0; t < NB; ++t) { double x = b2[t]; x += __shfl_xor(x, 16); x += __shfl_xor(x, 32); b2[t] = x; }
             double vr[NB];
-            if (probe) pk[5] = __builtin_amdgcn_s_memrealtime();
             solve_tiles<NB>(acc, b2, q, c, vr);
-            if (probe) pk[6] = __builtin_amdgcn_s_memrealtime();
             if (q == 0) {                                    // v_r | w_r -> scratch for the contraction kernel (NaN marks a failed sample)
               double* dst = ga->vw + s * (int64_t)(2 * R);
 #pragma unroll
@@ -1006,10 +996,6 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
               }
             }
             if (lane == 0) ga->J[s] = bad ? nanv : 0.5 * jl;
-            if (probe && lane == 0)
-              printf("[splitk probe] reduce %.2f us | chol %.2f | B_r %.2f | solve w_r %.2f | residual + rhs %.2f | solve v_r %.2f | total after main loop %.2f\n",
-                     (pk[1] - pk[0]) * 0.01, (pk[2] - pk[1]) * 0.01, (pk[3] - pk[2]) * 0.01, (pk[4] - pk[3]) * 0.01, (pk[5] - pk[4]) * 0.01,
-                     (pk[6] - pk[5]) * 0.01, (__builtin_amdgcn_s_memrealtime() - pk[0]) * 0.01);
             return;
           }
         }
@@ -1056,10 +1042,7 @@ __device__ __forceinline__ void rom_proj_entry_splitk(RomDev p, const double* __
   const unsigned long long ta = (unsigned long long)(theta + (int64_t)blockIdx.x * p.P);
   const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));
-  const long long t0 = __builtin_amdgcn_s_memrealtime();
-  if (p.clock_probe == 7 && s == 0 && threadIdx.x == 0) printf("[splitk probe] start tick %lld\n", t0);
   rom_proj_body<NB, 1, 0, true>(p, th[wave], s, lane, Ar, Br, factor, info, w_r, qoi_r, red_lds, theta_s, kpat, wave, KS, &ga);
-  if (p.clock_probe == 7 && s == 0 && threadIdx.x == 0) printf("[splitk probe] wave 0 whole kernel %.2f us\n", (__builtin_amdgcn_s_memrealtime() - t0) * 0.01);
 }
 
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
