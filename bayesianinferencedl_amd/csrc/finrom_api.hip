@@ -90,7 +90,7 @@ struct finrom_fom_s {
 struct finrom_rom_s {
   RomDev d{};
   std::vector<void*> owned;
-  Scratch Ar, Br, theta, qtmp, vw, ticket, grad_ticket;
+  Scratch Ar, Br, theta, qtmp, vw, ticket, grad_ticket, part;
   int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
   RomGramDev gram;                     // offline/online form (finrom_rom_set_gram); gram.h is filled at create
   int projection = FINROM_PROJECTION_DIRECT;
@@ -982,6 +982,7 @@ void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
   h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release(); h->ticket.release(); h->grad_ticket.release();
+  h->part.release();
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -1062,6 +1063,15 @@ int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r
   for (int64_t s0 = 0; s0 < S; s0 += chunk) {
     const int64_t Sc = std::min(chunk, S - s0);
     int rc;
+    // one-sample call patterns (MAP / HMC: a handful of samples, latency): contraction over several workgroups per sample, then
+    // the MFMA-form factorisation + substitutions (rom_onesample.hip)
+    if (A_r == nullptr && B_r == nullptr && h->projection == FINROM_PROJECTION_DIRECT && rom_onesample_applies(d, Sc) &&
+        getenv("FINROM_NO_FUSED_SOLVE") == nullptr && getenv("FINROM_NO_FUSED_CHOL") == nullptr) {
+      if ((rc = h->part.reserve(rom_onesample_scratch_bytes(d, Sc)))) return rc;
+      if ((rc = launch_rom_onesample(d, theta + s0 * d.P, Sc, (double*)h->part.p, 0, RomGradArgs(), w_r ? w_r + s0 * d.r : nullptr,
+                                     qoi_r ? qoi_r + s0 * d.n_obs : nullptr, info ? info + s0 : nullptr, st))) return rc;
+      continue;
+    }
     if ((rc = h->Ar.reserve((size_t)Sc * (d.rp * (d.rp + 1) / 2) * sizeof(double)))) return rc;
     if ((rc = h->Br.reserve((size_t)Sc * d.rp * sizeof(double)))) return rc;
     // A_r is factored inside the projection kernel (in registers, MFMA trailing updates) unless the caller
@@ -1122,6 +1132,26 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
     if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
     // one-sample call patterns (MAP / HMC), 48 < r <= 96, the per-sample contraction: projection split over four waves, both
     // solves in registers, the gradient contraction dealt over the same waves -- one kernel, nothing but the outputs written
+    if (h->projection == FINROM_PROJECTION_DIRECT && rom_onesample_applies(d, Sc) && getenv("FINROM_OLD_SUBST") == nullptr) {
+      // contraction over several workgroups per sample, MFMA-form factorisation + forward / adjoint solves (rom_onesample.hip),
+      // then the gradient contraction dealt over 36 workgroups per sample
+      RomGradArgs ga;
+      ga.data = data + (data_per_sample ? s0 * d.n_obs : 0); ga.data_stride = data_per_sample ? d.n_obs : 0;
+      ga.theta = theta + s0 * d.P; ga.J = J + s0; ga.g = g + s0 * d.P;
+      ga.npairs = h->g_npairs; ga.pair_p = h->g_pair_p; ga.pair_i = h->g_pair_i; ga.Gt = h->g_Gt;
+      const size_t vw_bytes = (size_t)Sc * 2 * d.rp * sizeof(double), gp_bytes = (size_t)Sc * ROM_GRAD_SMALL_NG * 32 * sizeof(double);
+      if ((rc = h->vw.reserve(vw_bytes + gp_bytes))) return rc;
+      if ((rc = h->part.reserve(rom_onesample_scratch_bytes(d, Sc)))) return rc;
+      if (!h->grad_ticket.p) {                          // arrival counters: zero once, the kernel leaves them zero
+        if ((rc = h->grad_ticket.reserve(ROM_SPLITK_MAX_S * sizeof(int)))) return rc;
+        FR_HIP(hipMemset(h->grad_ticket.p, 0, ROM_SPLITK_MAX_S * sizeof(int)));
+      }
+      ga.vw = (double*)h->vw.p; ga.gpart = (double*)((char*)h->vw.p + vw_bytes); ga.ticket = (int*)h->grad_ticket.p;
+      if ((rc = launch_rom_onesample(d, theta + s0 * d.P, Sc, (double*)h->part.p, 1, ga, w_r ? w_r + s0 * d.r : nullptr, q,
+                                     info ? info + s0 : nullptr, st))) return rc;
+      if ((rc = launch_rom_grad_contract_small(d, Sc, ga, st))) return rc;
+      continue;
+    }
     if (h->projection == FINROM_PROJECTION_DIRECT && rom_splitk_applies(d, Sc) && d.n_obs <= 64 && getenv("FINROM_OLD_SUBST") == nullptr) {
       RomGradArgs ga;
       ga.data = data + (data_per_sample ? s0 * d.n_obs : 0); ga.data_stride = data_per_sample ? d.n_obs : 0;

@@ -247,6 +247,11 @@ constexpr int ROM_SPLITK_MAX_S = 64;      // batches up to this size take the sp
 int launch_rom_proj_wide(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                          hipStream_t st, double* w_r, double* qoi_r);
 bool rom_splitk_applies(const RomDev& p, int64_t S);
+// one-sample call patterns (rom_onesample.hip): contraction over several workgroups per sample + MFMA-form solve kernel
+bool rom_onesample_applies(const RomDev& p, int64_t S);
+size_t rom_onesample_scratch_bytes(const RomDev& p, int64_t S);
+int launch_rom_onesample(const RomDev& p, const double* theta, int64_t S, double* part, int grad, const RomGradArgs& ga, double* w_r,
+                         double* qoi_r, int* info, hipStream_t st);
 constexpr int ROM_GRAD_SMALL_NG = 36;      // blocks per sample in rom_grad_contract_small_kernel
 int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st);
 int launch_rom_proj_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,

@@ -1,0 +1,350 @@
+// The one-sample call pattern of the reduced model (batches of <= 64 samples: MAP / HMC, BASELINE configs[4]): LATENCY, not
+// throughput.  AffineROMFin.forward_nine_param_reduced + qoi_reduced (rom/averaged_affine_ROM.py:278-333) and, with `grad`, the
+// adjoint solve of grad_reduced (:335-356) for a handful of samples whose inputs depend on the previous call's outputs.
+//
+// Round 2's kernel (rom_proj_splitk_kernel: the sample's k-steps over the four waves of ONE workgroup, wave 0 then factors and
+// substitutes by shuffle steps) took 178 us at r = 81; by phase clocks 76 us were the contraction, 23 us the factorisation and
+// 2 x 35 us the two pairs of substitutions (2 r dependent pivot steps each, an fp64 division and LDS-crossbar shuffles per step).
+// Two kernels here:
+//   rom_small_proj_kernel   the sample's k-steps over NC workgroups x 4 waves (one wave per SIMD of NC CUs); a workgroup adds its
+//                           four partial block triangles through LDS in a fixed order and writes ONE partial to global scratch;
+//   rom_small_solve_kernel  one workgroup per sample: its four waves add the NC partials (fixed order: deterministic), then
+//                           wave 0 factors and solves in MFMA form, LEFT-looking, with the tiles in LDS -- only one block row
+//                           of tiles is ever in registers, so hipcc's allocator has nothing to spill and the MFMA builtin (with
+//                           the compiler's own hazard handling) is good enough: this is one wave, not a pipe to keep full.
+//     forward   per block row kb: T(kb, tj) = A(kb, tj) - sum_{j < kb} U(j, kb)^T U(j, tj); the diagonal tile by 16 shuffle steps
+//               on [T_kk | I] (-> M_kb = U_kk^-T, carried transposed = as an A operand); U(kb, tj) = M_kb T(kb, tj) and the extra
+//               column Z_kb = M_kb (G_kb - sum_j U(j, kb)^T Z_j), G = [B_r | (B_obs Phi)^T]: 4 MFMAs per tile;
+//     middle    qoi_r = Z[:, 1:]^T Z[:, 0];  J;  U^-T (B_obs Phi)^T (data - qoi_r) = Z[:, 1:] (data - qoi_r) -- a combination of
+//               columns the forward sweep already produced: no second forward substitution;
+//     backward  ONE block substitution for both right-hand sides: X_kb = M_kb^T (R_kb - sum_{j > kb} U(kb, j) X_j); M_kb in its
+//               C/D layout IS the A operand of M_kb^T R, U(kb, j) is read from LDS transposed.  w_r = X[:, 0], v_r = X[:, 1].
+#include "rom_proj_device.h"
+
+namespace finrom {
+
+namespace {
+
+template <int NB> constexpr int onesample_nt() { return NB * (NB + 1) / 2; }
+
+// ---- contraction: partial block triangle of workgroup (s, j) ---------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S, int NC,
+                                                                double* __restrict__ part, const int* __restrict__ kpat) {
+  constexpr int NT = onesample_nt<NB>();
+  extern __shared__ __attribute__((aligned(16))) double red_lds[];      // 3 partial triangles: NT x 256 doubles each
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t s = blockIdx.x;
+  const int j = blockIdx.y;
+  const int q = lane >> 4, c = lane & 15;
+  const unsigned long long ta = (unsigned long long)(theta + s * p.P);
+  const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
+                                          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));
+  d4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+  // k-steps [k0, k0 + cnt) of the pattern-uniform tables; parts start at even k-steps (the loop is unrolled twice)
+  const int parts = 4 * NC, kpart = j * 4 + wave;
+  const int per = ((p.nku + parts - 1) / parts + 1) / 2 * 2, k0 = kpart * per;
+  const int cnt = k0 >= p.nku ? 0 : (p.nku - k0 < per ? p.nku - k0 : per);
+  if (cnt > 0) proj_main_uniform<NB>(p, kpat + 8 * k0, theta_s, q, c, acc, cnt);
+  mfma_drain(acc);
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) red_lds[((wave - 1) * NT + t) * 256 + g * 64 + lane] = acc[t][g];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+  for (int w = 1; w < 4; ++w)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) acc[t][g] += red_lds[((w - 1) * NT + t) * 256 + g * 64 + lane];
+  // tile t, natural layout: element (row q + 4 g, column c) at [t][(q + 4 g) * 16 + c]
+  double* __restrict__ dst = part + ((s * NC + j) * (int64_t)NT) * 256;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dst[t * 256 + (q + 4 * g) * 16 + c] = acc[t][g];
+}
+
+// ---- factorisation + forward / adjoint solves -------------------------------------------------------------------------------------
+typedef double v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4d mma(double a, double b, v4d cacc) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cacc, 0, 0, 0); }
+
+template <int NB> constexpr int small_solve_lds() { return onesample_nt<NB>() * 256 + NB * 256 + 16 * NB + 32 + 32; }
+
+template <int NB>
+__global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const double* __restrict__ theta, int64_t S, int NC,
+                                                                 const double* __restrict__ part, int grad, RomGradArgs ga,
+                                                                 double* __restrict__ w_r, double* __restrict__ qoi_r,
+                                                                 int* __restrict__ info) {
+  constexpr int NT = onesample_nt<NB>();
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* __restrict__ tl = lds;                      // [NT][256] A tiles, overwritten by U tiles; natural layout (row * 16 + col)
+  double* __restrict__ mbuf = tl + NT * 256;          // [NB][256] M_kb, natural layout
+  double* __restrict__ bl = mbuf + NB * 256;          // [16 NB] B_r
+  double* __restrict__ th = bl + 16 * NB;             // [32] 1, theta_1..P, 0
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t s = blockIdx.x;
+  const int q = lane >> 4, c = lane & 15;
+  // the NC partial triangles, added in a fixed order: tile t by wave t % 4
+  const double* __restrict__ src = part + (s * NC * (int64_t)NT) * 256;
+  for (int t = wave; t < NT; t += 4) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) a[g] += src[(j * NT + t) * 256 + g * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) tl[t * 256 + g * 64 + lane] = a[g];
+  }
+  if (wave == 0) {
+    if (lane == 0) { th[0] = 1.0; th[p.P + 1] = 0.0; }
+    if (lane < p.P) th[lane + 1] = theta[s * p.P + lane];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+
+  // B_r = psi^T F (rom :297): F is non-zero on the root nodes only; their rows of psi are rebuilt here
+  {
+    double bacc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
+    for (int ks = 0; ks < p.rhs_nk; ++ks) {
+      double v[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) v[b] = 0.0;
+      for (int t = 0; t < p.rhs_nt; ++t) {
+        const int row = (ks * p.rhs_nt + t) * 4 + q;
+        const double thp = th[p.rhs_pidx[row]];
+        const double* rsrc = p.rhs_tv + (int64_t)row * p.rp + c;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) v[b] = fma(thp, rsrc[16 * b], v[b]);
+      }
+      const double fk = p.rhs_f[ks * 4 + q];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) bacc[b] = fma(v[b], fk, bacc[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double x = bacc[b];
+      x += __shfl_xor(x, 16);
+      x += __shfl_xor(x, 32);
+      if (q == 0) bl[16 * b + c] = x;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  auto tile_at = [&](int ti, int tj) -> double* { return tl + (ti * NB - (ti * (ti - 1)) / 2 + (tj - ti)) * 256; };
+  const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.obs_phi), 0, p.n_obs * p.r * 8, 0x00020000);
+  const int ovoff = ((c - 1) * p.r + q) * 8;            // row q of observation c - 1 (c == 0 and c > n_obs: out of range, reads 0)
+  const int nat = q * 16 + c, trn = c * 16 + q;         // natural / transposed offset of element (q, c) inside a tile: + 64 g / + 4 g
+  int bad = 0;
+  v4d z[NB];
+  // ---- forward ---------------------------------------------------------------------------------------------------------------
+  sfor<0, NB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+    v4d T[NB - kb];
+    sfor<kb, NB>([&](auto jc) {
+      constexpr int tj = decltype(jc)::value;
+      const double* at = tile_at(kb, tj);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) T[tj - kb][g] = at[nat + 64 * g];
+    });
+    v4d e;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int row = 16 * kb + q + 4 * g;
+      double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ores, ovoff, (16 * kb + 4 * g) * 8, 0));
+      if (row >= p.r) v = 0.0;
+      if (c == 0) v = bl[row];
+      e[g] = v;
+    }
+    // padding rows / columns (>= r) of psi^T psi are zero: unit diagonal
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (q + 4 * g == c && 16 * kb + c >= p.r) T[0][g] = 1.0;
+    // left-looking: minus what the block rows above contribute (their U tiles in LDS, natural layout = the operand layouts)
+    sfor<0, kb>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const double* ujk = tile_at(j, kb);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const double ua = -ujk[nat + 64 * g];           // A operand of k-step g: U(j, kb)[k = q + 4 g][i = c]
+        sfor<kb, NB>([&](auto tc) {
+          constexpr int tj = decltype(tc)::value;
+          T[tj - kb] = mma(ua, tile_at(j, tj)[nat + 64 * g], T[tj - kb]);
+        });
+        e = mma(ua, z[j][g], e);
+      }
+    });
+    // (a) the diagonal tile: 16 elimination steps on [T_kk | I]; M^T is carried (column operations), which is M as an A operand
+    double Am[4];
+    {
+      v4d& D = T[0];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Am[g] = (q + 4 * g == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int gs = 0; gs < 4; ++gs)
+#pragma unroll 1
+        for (int qs = 0; qs < 4; ++qs) {
+          const int st = 4 * gs + qs;
+          const double piv = read_lane_f64(D[gs], qs * 16 + st);
+          bad |= !(piv > 0.0);
+          double rinv = __builtin_amdgcn_rsq(piv);
+#pragma unroll
+          for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
+          D[gs] *= (q == qs) ? rinv : 1.0;
+          const double rvD = __shfl(D[gs], qs * 16 + c);
+          const double mcol = (c > st) ? rvD : 0.0, scol = (c == st) ? rinv : 1.0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (g <= gs) {
+              Am[g] *= scol;
+              Am[g] = fma(-mcol, __shfl(Am[g], q * 16 + st), Am[g]);
+            }
+            if (g >= gs) {
+              const double v = __shfl(D[gs], qs * 16 + ((q + 4 * g) & 15));
+              const double m = (q + 4 * g > st) ? v : 0.0;
+              D[g] = fma(-m, rvD, D[g]);
+            }
+          }
+        }
+    }
+    // M_kb, natural layout, for the backward sweep: Am[g] at lane (q, c) is M[c][q + 4 g]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mbuf[kb * 256 + trn + 4 * g] = Am[g];
+    // (b) U(kb, tj) = M T(kb, tj), Z_kb = M e
+    sfor<kb + 1, NB>([&](auto jc) {
+      constexpr int tj = decltype(jc)::value;
+      v4d n = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) n = mma(Am[g], T[tj - kb][g], n);
+      double* ut = tile_at(kb, tj);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) ut[nat + 64 * g] = n[g];
+    });
+    {
+      v4d n = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) n = mma(Am[g], e[g], n);
+      z[kb] = n;
+    }
+    __builtin_amdgcn_wave_barrier();
+  });
+  // ---- middle ----------------------------------------------------------------------------------------------------------------
+  double part_q = 0.0;
+  sfor<0, NB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) part_q = fma(z[kb][g], __shfl(z[kb][g], q * 16), part_q);
+  });
+  part_q += __shfl_xor(part_q, 16);
+  part_q += __shfl_xor(part_q, 32);                     // lane column c = o + 1: qoi_r[o]
+  const double nanv = __builtin_nan("");
+  if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
+  if (qoi_r != nullptr && lane >= 1 && lane <= p.n_obs) qoi_r[s * p.n_obs + lane - 1] = bad ? nanv : part_q;
+  if (grad) {
+    const double* dat = ga.data + (ga.data_stride ? s * ga.data_stride : 0);
+    const bool ocol = c >= 1 && c <= p.n_obs;
+    const double res = ocol ? dat[c - 1] - part_q : 0.0;
+    double r2 = (q == 0) ? res * res : 0.0;
+    for (int off = 8; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
+    if (lane == 0) ga.J[s] = bad ? nanv : 0.5 * r2;
+    // y2[row] = sum_o Z[row][o + 1] resid[o] -> column 1 of the tile column (column 0 keeps Z[:, 0])
+    sfor<0, NB>([&](auto kc) {
+      constexpr int kb = decltype(kc)::value;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        double t = z[kb][g] * res;
+        for (int off = 8; off > 0; off >>= 1) t += __shfl_xor(t, off);
+        if (c == 1) z[kb][g] = t;
+      }
+    });
+  }
+  // ---- backward: X_kb = M_kb^T (R_kb - sum_{j > kb} U(kb, j) X_j); X overwrites Z block by block ----------------------------------
+  sfor<0, NB>([&](auto kc) {
+    constexpr int kb = NB - 1 - decltype(kc)::value;
+    v4d rr = z[kb];
+    sfor<kb + 1, NB>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const double* ukj = tile_at(kb, j);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rr = mma(-ukj[trn + 4 * g], z[j][g], rr);      // A operand: U(kb, j)[i = c][k = q + 4 g]
+    });
+    v4d n = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) n = mma(mbuf[kb * 256 + nat + 64 * g], rr[g], n);   // A operand of M^T R: M[k = q + 4 g][i = c]
+    z[kb] = n;
+  });
+  const int R = p.rp;
+  if (c <= 1) {                                         // column 0 of X is w_r, column 1 v_r
+    double* dst = grad ? ga.vw + s * (int64_t)(2 * R) + (c == 0 ? R : 0) : nullptr;
+    sfor<0, NB>([&](auto kc) {
+      constexpr int kb = decltype(kc)::value;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = 16 * kb + q + 4 * g;
+        const double v = row < p.r ? (bad ? nanv : z[kb][g]) : 0.0;
+        if (dst != nullptr) dst[row] = v;
+        if (c == 0 && w_r != nullptr && row < p.r) w_r[s * p.r + row] = v;
+      }
+    });
+  }
+}
+
+template <int NB>
+int launch_small(const RomDev& p, const double* theta, int64_t S, int NC, double* part, int grad, const RomGradArgs& ga, double* w_r,
+                 double* qoi_r, int* info, hipStream_t st) {
+  constexpr int lds_a = 3 * onesample_nt<NB>() * 256 * (int)sizeof(double), lds_b = small_solve_lds<NB>() * (int)sizeof(double);
+  static PerDeviceOnce once;
+  if (int rc = once.run([&]() -> int {
+        FR_HIP(hipFuncSetAttribute((const void*)rom_small_proj_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+        FR_HIP(hipFuncSetAttribute((const void*)rom_small_solve_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+        return 0; })) return rc;
+  {
+    ScopedKernelTimer t(K_ROM_PROJ, st);
+    hipLaunchKernelGGL(rom_small_proj_kernel<NB>, dim3((unsigned)S, (unsigned)NC), dim3(256), lds_a, st, p, theta, S, NC, part, p.kmeta);
+    FR_HIP(hipGetLastError());
+  }
+  ScopedKernelTimer t(K_ROM_SOLVE, st);
+  hipLaunchKernelGGL(rom_small_solve_kernel<NB>, dim3((unsigned)S), dim3(256), lds_b, st, p, theta, S, NC, part, grad, ga, w_r, qoi_r, info);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// workgroups per sample of the contraction: as many as keep a part at >= 8 k-steps per wave, at most 8 (NC x 4 SIMDs of NC CUs)
+int rom_onesample_parts(const RomDev& p, int64_t S) {
+  static const int forced = getenv("FINROM_ONESAMPLE_NC") != nullptr ? atoi(getenv("FINROM_ONESAMPLE_NC")) : 0;
+  if (forced > 0) return forced > 16 ? 16 : forced;
+  int nc = p.nku / 32;
+  if (nc > 8) nc = 8;
+  if (S > 8 && nc > 4) nc = 4;
+  return nc < 1 ? 1 : nc;
+}
+size_t rom_onesample_scratch_bytes(const RomDev& p, int64_t S) {
+  return (size_t)S * rom_onesample_parts(p, S) * (p.NB * (p.NB + 1) / 2) * 256 * sizeof(double);
+}
+bool rom_onesample_applies(const RomDev& p, int64_t S) {
+  static const bool off = getenv("FINROM_NO_ONESAMPLE") != nullptr;
+  return !off && S <= ROM_SPLITK_MAX_S && p.NB >= 1 && p.NB <= 6 && p.nku >= 64 && p.n_obs <= 15;
+}
+
+// grad = 0: w_r (optional) and qoi_r; grad = 1 (ga.data, ga.vw, ga.J set): also v_r; v_r | w_r go to ga.vw for the contraction kernel
+int launch_rom_onesample(const RomDev& p, const double* theta, int64_t S, double* part, int grad, const RomGradArgs& ga, double* w_r,
+                         double* qoi_r, int* info, hipStream_t st) {
+  if (S == 0) return 0;
+  const int NC = rom_onesample_parts(p, S);
+  switch (p.NB) {
+#define FR_ONE(N) case N: return launch_small<N>(p, theta, S, NC, part, grad, ga, w_r, qoi_r, info, st);
+    FR_ONE(1) FR_ONE(2) FR_ONE(3) FR_ONE(4) FR_ONE(5) FR_ONE(6)
+#undef FR_ONE
+    default: set_error("rom_onesample: basis size"); return FINROM_ERR_UNSUPPORTED;
+  }
+}
+
+}  // namespace finrom
