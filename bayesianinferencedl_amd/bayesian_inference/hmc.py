@@ -92,3 +92,109 @@ def romml_value_and_grad(solver_r):
         res = solver_r.grad_romml_batch(K)
         return np.asarray(res["loss"]), np.asarray(res["grad"]), np.asarray(res["info"]) != 0
     return f
+
+
+def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, sigma=0.05, tau=0.5, mean=None, record=None,
+                      keep_trace=False, graph=True, data=None):
+    """`run_chains` with the chains' state RESIDENT ON THE DEVICE (torch tensors on the current CUDA device): positions, momenta and
+    potential gradients never visit the host inside a trajectory.  One leapfrog step = a few elementwise kernels around ONE
+    library call (finrom_romml_grad on the tensors in place); with graph=True that step is captured once in a HIP graph
+    (torch.cuda.CUDAGraph: the library launches on torch's capture stream) and replayed, so a step costs the host one graph
+    launch.  The host sees two scalars per chain and proposal (the Hamiltonians, for the Metropolis test with the same NumPy
+    streams as run_chains) -- one synchronisation per proposal instead of three copies and one per evaluation.
+
+    Same chains as run_chains(romml_value_and_grad(solver_r), ...) up to the rounding of the elementwise updates.
+    Returns HmcResult(K [C, n] (NumPy), accept, proposals, n_evals, recorded, trace, graph: whether a graph was replayed)."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f64 = dict(dtype=torch.float64, device=dev)
+    K = torch.as_tensor(np.ascontiguousarray(K0, dtype=np.float64), **f64).clone()
+    C, n = K.shape
+    mean_t = K.clone() if mean is None else torch.as_tensor(np.broadcast_to(np.asarray(mean, dtype=np.float64), (C, n)).copy(), **f64)
+    data_t = torch.as_tensor(np.ascontiguousarray(solver_r.data if data is None else data, dtype=np.float64), **f64)
+    rngs = [np.random.default_rng(s) for s in seeds]
+    assert len(rngs) == C
+    c_lik, c_pri = 1.0 / sigma ** 2, 1.0 / tau ** 2
+    Kq, Pq, D, dUq = (torch.empty_like(K) for _ in range(4))
+    out = {}
+
+    def evaluate():
+        """dUq, out <- value and gradient at Kq (all static tensors: the same buffers at every call once captured)."""
+        res = solver_r.grad_romml_batch(Kq, data=data_t)
+        torch.sub(Kq, mean_t, out=D)
+        torch.add(res["grad"] * c_lik, D, alpha=c_pri, out=dUq)
+        dUq.masked_fill_(res["info"].ne(0)[:, None], 0.0)           # an indefinite reduced operator: no force, rejected below
+        out["loss"], out["grad"], out["info"] = res["loss"], res["grad"], res["info"]
+
+    def step():
+        Kq.add_(Pq, alpha=eps)
+        evaluate()
+        Pq.add_(dUq, alpha=-eps)                                   # two half steps; the ends of a trajectory correct by +- eps/2
+
+    def potential_now():
+        U = out["loss"] * c_lik + 0.5 * c_pri * (D * D).sum(1)
+        return torch.where(out["info"].ne(0) | ~torch.isfinite(U), torch.full_like(U, float("inf")), U)
+
+    recorded, evals = [], 0
+
+    def note():
+        nonlocal evals
+        if record is not None and evals in record:
+            recorded.append((evals, Kq.cpu().numpy().copy(), out["loss"].cpu().numpy().copy(), out["grad"].cpu().numpy().copy()))
+        evals += 1
+
+    Kq.copy_(K); Pq.zero_()
+    evaluate()                                                      # evaluation 0: the starting point (also warms the library up)
+    note()
+    U = potential_now()
+    if not bool(torch.isfinite(U).all()):
+        raise ValueError("HMC start point has an indefinite reduced operator")
+    dU = dUq.clone()
+    g = None
+    if graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                           # warm-up on a side stream, as torch's graph recipe asks
+                Kq_save, Pq_save, d_save = Kq.clone(), Pq.clone(), dUq.clone()
+                for _ in range(2):
+                    step()
+                Kq.copy_(Kq_save); Pq.copy_(Pq_save); dUq.copy_(d_save)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            Kq.copy_(Kq_save); Pq.copy_(Pq_save); dUq.copy_(d_save)      # (the capture does not run the step; restore anyway)
+        except Exception as exc:                                    # no graph support for this sequence: plain stream order
+            import warnings
+            warnings.warn(f"hmc: HIP graph capture failed ({exc!r}); the leapfrog steps are launched one by one")
+            g = None
+    trace = [K.cpu().numpy().copy()] if keep_trace else None
+    accept = np.zeros(C, np.int64)
+    proposals = 0
+    P_host = np.empty((C, n))
+    while evals + n_leapfrog <= n_evals:
+        for c_, r in enumerate(rngs):
+            P_host[c_] = r.standard_normal(n)
+        P0 = torch.as_tensor(P_host, **f64)
+        H0 = U + 0.5 * (P0 * P0).sum(1)
+        Kq.copy_(K); dUq.copy_(dU)
+        torch.add(P0, dUq, alpha=-0.5 * eps, out=Pq)                # first half step
+        for _ in range(n_leapfrog):
+            g.replay() if g is not None else step()
+            note()
+        Pq.add_(dUq, alpha=0.5 * eps)                               # the last update was a whole step: back to a half
+        Uq = potential_now()
+        H1 = Uq + 0.5 * (Pq * Pq).sum(1)
+        h = torch.stack([H0, H1]).cpu().numpy()                     # the proposal's one synchronisation
+        u = np.array([r.uniform() for r in rngs])
+        with np.errstate(over="ignore", invalid="ignore"):
+            ok = np.isfinite(h[1]) & (np.log(u) < h[0] - h[1])
+        ok_t = torch.as_tensor(ok, device=dev)
+        K = torch.where(ok_t[:, None], Kq, K); U = torch.where(ok_t, Uq, U); dU = torch.where(ok_t[:, None], dUq, dU)
+        accept += ok
+        proposals += 1
+        if keep_trace:
+            trace.append(K.cpu().numpy().copy())
+    return HmcResult(K=K.cpu().numpy(), accept=accept, proposals=proposals, n_evals=evals, recorded=recorded,
+                     trace=np.stack(trace) if keep_trace else None, graph=g is not None)

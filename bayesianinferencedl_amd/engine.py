@@ -61,11 +61,12 @@ class _Batch:
     # them) -- a one-sample call is dominated by driver round trips, not by the kernels (the MAP / HMC pattern of configs[4]).
     _ARENA_MIN = 64 << 10
 
-    def new(self, shape, dtype="f8"):
-        """Allocate a zero-filled output of the same kind; returns (handle, device pointer)."""
+    def new(self, shape, dtype="f8", zero=True):
+        """Allocate an output of the same kind, zero-filled unless the call overwrites all of it (zero=False: one fill kernel
+        less per output on the torch path -- they add up in a one-sample call); returns (handle, device pointer)."""
         if self.torch:
             import torch
-            t = torch.zeros(shape, dtype=torch.float64 if dtype == "f8" else torch.int32, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=torch.float64 if dtype == "f8" else torch.int32, device=self.device)
             return t, t.data_ptr()
         n = int(np.prod(shape)) * (8 if dtype == "f8" else 4)
         arenas = self.__dict__.setdefault("_arenas", [])
@@ -528,7 +529,8 @@ def romml_grad(rom, mlp, Sop_buf, K, data):
     data = data if _is_torch(data) else np.ascontiguousarray(data, dtype=np.float64)
     per_sample = 1 if data.ndim == 2 else 0
     db = _Batch(data, n_obs)
-    grad, gp = b.new((S, n)); loss, lp = b.new((S,)); q, qp = b.new((S, n_obs)); e, ep = b.new((S, n_obs)); info, ip = b.new((S,), "i4")
+    grad, gp = b.new((S, n), zero=False); loss, lp = b.new((S,), zero=False); q, qp = b.new((S, n_obs), zero=False)
+    e, ep = b.new((S, n_obs), zero=False); info, ip = b.new((S,), "i4")
     check(lib().finrom_romml_grad(rom._h, mlp._h, Sop_buf.ptr, b.ptr, db.ptr, per_sample, S, gp, lp, qp, ep, ip, b.stream),
           "finrom_romml_grad")
     _sync_if_mixed(b, db)

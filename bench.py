@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (vendor; = 256 CU * 4 SIMD * 32 FLOP/clk * 2.4 GHz)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HMC_EPS = 2e-2                   # leapfrog step of the configs[4] rehearsal (tuned on the box for 60-90 % acceptance, see DESIGN)
 
 
 def parse():
@@ -50,6 +51,11 @@ def parse():
                     help="pairs: the FOM+ROM dataset loop (BASELINE metric, configs[1..3]); hmc: BASELINE configs[4], chains of "
                          "sequential dependent one-sample ROM + learned-error value-and-gradient calls (steps = calls per chain)")
     ap.add_argument("--chains", type=int, default=4, help="hmc: number of independent chains (sharded over the GPUs)")
+    ap.add_argument("--hmc-mode", default="device", choices=["device", "host"],
+                    help="hmc: 'device' keeps positions / momenta / gradients in HBM across a trajectory and replays one captured "
+                         "HIP graph per leapfrog step (hmc.run_chains_device); 'host' is round 2's NumPy recursion around one library "
+                         "call per evaluation (three copies and a synchronisation each)")
+    ap.add_argument("--hmc-eps", type=float, default=None, help="hmc: leapfrog step size (default: tuned for 60-90 %% acceptance)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 run: nccl (= RCCL over xGMI, one rank per GPU) or gloo (host "
                          "gather; ranks may then share a GPU: rehearsal of the N > 1 path on a one-GPU box)")
@@ -413,16 +419,25 @@ def run_hmc(args, rank, local_rank, world):
     K0 = np.stack([np.exp(0.1 * np.random.default_rng(6 + c).standard_normal(V.dim())) for c in mine]) if mine else np.zeros((0, V.dim()))
     f = hmc.romml_value_and_grad(solver_r)
     L = 10
-    steps = args.steps if args.steps >= L else 2000         # (a step = one evaluation here; fewer than one trajectory: the default length)
+    steps = args.steps if args.steps >= L else 10000        # (a step = one evaluation here; fewer than one trajectory: configs[4]'s 10k)
     n_evals = 1 + steps // L * L                            # evaluation 0 (the start point) + whole trajectories
+    eps = args.hmc_eps if args.hmc_eps is not None else HMC_EPS
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(n):
-        return hmc.run_chains(f, K0, n, seeds=[6 + c for c in mine], n_leapfrog=L) if mine else None
+    seeds = [1000 + c for c in mine]                       # (K0 came from default_rng(6 + c): the chains' streams are others)
+
+    def run(n, k0=None, sd=None):
+        k0 = K0 if k0 is None else k0
+        sd = seeds if sd is None else sd
+        if not mine:
+            return None
+        if args.hmc_mode == "device":
+            return hmc.run_chains_device(solver_r, k0, n, seeds=sd, n_leapfrog=L, eps=eps)
+        return hmc.run_chains(f, k0, n, seeds=sd, n_leapfrog=L, eps=eps)
     run(1 + max(L, args.warmup // L * L))
     fence()
     Lb = _ffi.lib()
@@ -441,10 +456,12 @@ def run_hmc(args, rank, local_rank, world):
     # one chain alone, one sample per call: the per-call latency a single PyMC chain would see (not timed above)
     lat = None
     if rank == 0 and mine:
-        n1 = 1 + min(200, args.steps) // L * L
-        hmc.run_chains(f, K0[:1], 1 + L, seeds=[6], n_leapfrog=L)
+        n1 = 1 + min(1000, steps) // L * L
+        run(1 + L, K0[:1], seeds[:1])
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
-        hmc.run_chains(f, K0[:1], n1, seeds=[6], n_leapfrog=L)
+        run(n1, K0[:1], seeds[:1])
+        torch.cuda.synchronize()
         lat = (time.perf_counter() - t1) / n1
     if rank == 0:
         total = args.chains * n_evals
@@ -480,7 +497,9 @@ def run_hmc(args, rank, local_rank, world):
                                    f"(n={V.dim()}), r={r}, res_bn_fc error model 5 x 50, {L} leapfrog steps per proposal, "
                                    f"{len(mine)} chains per call on rank 0", "chains": args.chains, "evals_per_chain": n_evals,
                        "r": r, "projection": args.projection, "accepted": res["accept"].tolist() if res else None,
-                       "proposals": res["proposals"] if res else None},
+                       "proposals": res["proposals"] if res else None, "eps": eps, "mode": args.hmc_mode,
+                       "hip_graph": bool(res.get("graph")) if res else None,
+                       "acceptance": float(np.mean(res["accept"]) / max(res["proposals"], 1)) if res else None},
             "roofline": roof, "cpu_baseline": cpu, "single_chain_latency_ms_per_call": None if lat is None else 1e3 * lat,
             "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0}}), flush=True)
     if world > 1:

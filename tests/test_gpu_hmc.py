@@ -60,6 +60,36 @@ def test_hmc_chains_value_and_gradient_match_the_oracle(setup, projection):
     assert np.linalg.norm(solo.K[0] - lock.K[1]) <= 1e-6 * np.linalg.norm(lock.K[1])
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_device_resident_chains_walk_the_host_chains_path(setup, graph):
+    """hmc.run_chains_device -- positions, momenta and gradients stay on the device, one captured HIP graph per leapfrog step
+    (graph=True) or the same launches in stream order -- must walk the path of the host recursion with the same seeds
+    (the elementwise updates round differently: 1e-9), accept the same proposals, and its recorded evaluations must match
+    the oracle like the host chain's do.  eps large enough that proposals ARE rejected (a chain that accepts everything does
+    not exercise the accept / reject bookkeeping)."""
+    from bayesianinferencedl_amd.bayesian_inference import hmc
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    V, phi, model, data, ro = setup
+    rom = AffineROMFin(V, model, phi); rom.set_data(data)
+    chains = [0, 1, 2, 3]
+    K0 = np.stack([np.exp(0.1 * np.random.default_rng(6 + c).standard_normal(V.dim())) for c in chains])
+    kw = dict(seeds=[100 + c for c in chains], eps=3e-2, n_leapfrog=10)
+    want = {0, 1, 10, 55, 120}
+    host = hmc.run_chains(hmc.romml_value_and_grad(rom), K0, 121, record=want, **kw)
+    dev = hmc.run_chains_device(rom, K0, 121, record=want, graph=graph, **kw)
+    assert dev.graph == graph, "HIP graph capture of the leapfrog step failed" if graph else "graph not requested"
+    assert dev.n_evals == host.n_evals == 121 and dev.proposals == host.proposals == 12
+    assert 0 < host.accept.sum() < 4 * 12, host.accept           # some accepted, some rejected
+    assert np.array_equal(dev.accept, host.accept)
+    assert np.linalg.norm(dev.K - host.K) <= 1e-9 * np.linalg.norm(host.K)
+    assert [e for e, *_ in dev.recorded] == [e for e, *_ in host.recorded]
+    for (ev, K, loss, grad), (_, Kh, lossh, gradh) in zip(dev.recorded, host.recorded):
+        assert np.linalg.norm(K - Kh) <= 1e-9 * np.linalg.norm(Kh), ev
+        assert np.linalg.norm(grad - gradh) <= 1e-6 * np.linalg.norm(gradh), ev
+        go, lo = O.grad_romml_oracle(ro, model, K[2])
+        assert abs(loss[2] - lo) <= 2e-5 * abs(lo) and np.linalg.norm(grad[2] - go) <= 1e-5 * np.linalg.norm(go), ev
+
+
 def test_bench_hmc_mode_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "hmc", "--steps", "40", "--warmup", "10",
                         "--cpu-samples", "4"], capture_output=True, text=True, timeout=900)
