@@ -133,10 +133,37 @@ def lib_path() -> str:
     return os.environ.get("FINROM_LIB", _build.LIB)
 
 
+def _share_torch_hip_runtime():
+    """ONE HIP / HSA runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so.7 + libhsa-runtime64.so.1; this
+    library is linked against /opt/rocm's.  With torch imported first the loader resolves our DT_NEEDED to torch's copy (same
+    SONAME) and everything shares one runtime; with OUR library loaded first the process ends up with two HSA runtimes and the
+    second one to initialise (torch) finds no GPU ("No HIP GPUs are available").  So: if torch is installed and not yet imported,
+    its two runtime libraries are loaded first, without importing torch.  FINROM_SYSTEM_HIP=1 keeps /opt/rocm's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FINROM_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    d = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(d, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load (once) and return the shared library; raise loudly if it is not built."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         path = lib_path()
         if not os.path.exists(path):
             raise FinromError(
