@@ -48,6 +48,10 @@ static hipEvent_t get_event() {
 ScopedKernelTimer::ScopedKernelTimer(int slot_, hipStream_t s_) : slot(slot_), s(s_) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_on) return;
+  // a stream that is being captured into a HIP graph records nothing now: an event recorded there becomes a graph node and can
+  // never be waited for or timed from the host (hmc.run_chains_device captures the one-sample call sequence)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
   e0 = get_event(); e1 = get_event();
   if (e0 && e1) (void)hipEventRecord(e0, s);
 }

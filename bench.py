@@ -447,6 +447,13 @@ def run_hmc(args, rank, local_rank, world):
     fence()
     dt = time.perf_counter() - t0
     Lb.finrom_profile_enable(0)
+    if args.hmc_mode == "device" and not args.no_profile and mine:
+        # kernels replayed from a HIP graph cannot be bracketed with events: per-kernel times come from a short pass of the same
+        # chains with the launches in stream order (not timed)
+        Lb.finrom_profile_reset(); Lb.finrom_profile_enable(1)
+        hmc.run_chains_device(solver_r, K0, 1 + 20 * L, seeds=seeds, n_leapfrog=L, eps=eps, graph=False)
+        torch.cuda.synchronize()
+        Lb.finrom_profile_enable(0)
     prof = _ffi.profile_read()
     cdev = dev if args.backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
