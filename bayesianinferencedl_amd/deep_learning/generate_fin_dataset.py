@@ -60,12 +60,21 @@ def gen_affine_avg_rom_dataset(dataset_size, resolution=40, genrand=False, *, ph
         names = {"z": f"z_aff_avg_{first}_avg_obs_3.npy", "err": f"errors_aff_avg_{first}_avg_obs_3.npy", "qoi": f"qois_avg_{first}_avg_obs_3.npy"}
         paths = {k: os.path.join(out_dir, v) for k, v in names.items()}
         shapes = {"z": (dataset_size, n), "err": (dataset_size, n_obs), "qoi": (dataset_size, n_obs)}
+        # what a resumed run must share with the interrupted one: sizes, stream, AND the operators the samples go through -- a
+        # rerun with another basis, observation set or covariance factor must not continue into the same files
+        import hashlib
+        hsh = hashlib.sha256()
+        for a_ in (phi, chol):
+            hsh.update(np.ascontiguousarray(a_, dtype=np.float64).tobytes())
         meta = {"dataset_size": int(dataset_size), "seed": seed, "batch": int(batch), "n": int(n), "n_obs": int(n_obs),
-                "device_rng": bool(device_rng)}
+                "device_rng": bool(device_rng), "genrand": bool(genrand), "operators_sha256": hsh.hexdigest()}
         prog_path = os.path.join(out_dir, f".gen_affine_avg_rom_dataset_{first}.progress.json")
         if seed is not None and os.path.exists(prog_path) and all(os.path.exists(p_) for p_ in paths.values()):
-            with open(prog_path) as f:
-                prev = json.load(f)
+            try:
+                with open(prog_path) as f:
+                    prev = json.load(f)
+            except (OSError, ValueError):                   # killed while the side file was being written: start over
+                prev = {}
             if {k: prev.get(k) for k in meta} == meta:
                 done = int(prev.get("done", 0))
         mode = "r+" if done else "w+"
@@ -96,9 +105,10 @@ def gen_affine_avg_rom_dataset(dataset_size, resolution=40, genrand=False, *, ph
         if tags:
             for a_ in (z_s, qoi_errors, qois):
                 a_.flush()
-            if seed is not None:
-                with open(prog_path, "w") as f:
+            if seed is not None:                            # (through a temporary file: a kill leaves the old or the new one)
+                with open(prog_path + ".tmp", "w") as f:
                     json.dump(dict(meta, done=ib + 1), f)
+                os.replace(prog_path + ".tmp", prog_path)
     if tags and prog_path and os.path.exists(prog_path) and (_stop_after_batches is None):
         os.remove(prog_path)
     return (z_s, qoi_errors)

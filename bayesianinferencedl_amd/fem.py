@@ -40,6 +40,12 @@ def deterministic_blas():
     try:
         from threadpoolctl import threadpool_limits
     except ImportError:
+        import os
+        import warnings
+        if os.environ.get("OMP_NUM_THREADS") != "1":
+            warnings.warn("threadpoolctl is not installed and OMP_NUM_THREADS != 1: the one-time dense host products may be summed "
+                          "in a thread-count-dependent order, so outputs are no longer guaranteed bit-identical across rank counts "
+                          "(set OMP_NUM_THREADS=1 or install threadpoolctl)", RuntimeWarning, stacklevel=3)
         yield
         return
     with threadpool_limits(limits=1):

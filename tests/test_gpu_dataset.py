@@ -138,6 +138,20 @@ def test_dataset_is_streamed_shard_by_shard_and_resumes(tmp_path, problems):
     for name in ("z_aff_avg_tr_avg_obs_3", "errors_aff_avg_tr_avg_obs_3", "qois_avg_tr_avg_obs_3"):
         assert np.array_equal(np.load(a / (name + ".npy")), np.load(b / (name + ".npy")))
     assert np.array_equal(z1, z2) and np.array_equal(e1, e2)
+    # a rerun with ANOTHER basis must not continue into the interrupted files (the side file records a hash of the operators),
+    # and a side file cut off by a kill means "start over", not a crash in json.load
+    phi2 = O.pod_basis(Y[::-1] ** 1.5, 8)
+    f_, g_ = tmp_path / "f", tmp_path / "g"
+    f_.mkdir(); g_.mkdir()
+    gen_affine_avg_rom_dataset(S, resolution=14, phi=phi, seed=7, out_dir=str(f_), batch=512, _stop_after_batches=2)
+    z5, e5 = gen_affine_avg_rom_dataset(S, resolution=14, phi=phi2, seed=7, out_dir=str(f_), batch=512)
+    z6, e6 = gen_affine_avg_rom_dataset(S, resolution=14, phi=phi2, seed=7, out_dir=str(g_), batch=512)
+    assert np.array_equal(e5, e6) and not np.array_equal(e5, e1)
+    gen_affine_avg_rom_dataset(S, resolution=14, phi=phi, seed=7, out_dir=str(g_), batch=512, _stop_after_batches=1)
+    with open(g_ / ".gen_affine_avg_rom_dataset_tr.progress.json", "w") as fh:
+        fh.write('{"dataset_size": 13')
+    z7, e7 = gen_affine_avg_rom_dataset(S, resolution=14, phi=phi, seed=7, out_dir=str(g_), batch=512)
+    assert np.array_equal(z7, z1) and np.array_equal(e7, e1)
     # device-drawn xi: the global sample index keys the stream, so the shard size does not matter
     c, d = tmp_path / "c", tmp_path / "d"
     c.mkdir(); d.mkdir()
