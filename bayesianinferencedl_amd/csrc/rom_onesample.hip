@@ -317,13 +317,13 @@ int launch_small(const RomDev& p, const double* theta, int64_t S, int NC, double
 
 }  // namespace
 
-// workgroups per sample of the contraction: as many as keep a part at >= 8 k-steps per wave, at most 8 (NC x 4 SIMDs of NC CUs)
-int rom_onesample_parts(const RomDev& p, int64_t S) {
+// workgroups per sample of the contraction: as many as keep a part at >= 8 k-steps per wave, at most 8 (NC x 4 SIMDs of NC CUs).
+// NOT a function of the batch size: a sample's sums are split the same way alone and inside a batch of 64 (bit-identical results)
+int rom_onesample_parts(const RomDev& p, int64_t /*S*/) {
   static const int forced = getenv("FINROM_ONESAMPLE_NC") != nullptr ? atoi(getenv("FINROM_ONESAMPLE_NC")) : 0;
   if (forced > 0) return forced > 16 ? 16 : forced;
   int nc = p.nku / 32;
   if (nc > 8) nc = 8;
-  if (S > 8 && nc > 4) nc = 4;
   return nc < 1 ? 1 : nc;
 }
 size_t rom_onesample_scratch_bytes(const RomDev& p, int64_t S) {
