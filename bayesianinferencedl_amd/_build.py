@@ -11,8 +11,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfinrom_hip.so")
-SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip"]
-HEADERS = [os.path.join(CSRC, "finrom_internal.h"), os.path.join(CSRC, "rom_proj_device.h"), os.path.join(ROOT, "include", "finrom.h")]
+SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip"]
+HEADERS = [os.path.join(CSRC, "finrom_internal.h"), os.path.join(CSRC, "rom_proj_device.h"), os.path.join(CSRC, "fom_band_device.h"), os.path.join(ROOT, "include", "finrom.h")]
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 # rom_proj_single.hip is built at -O2: at -O3 hipcc's extra passes inflate the register pressure of the r = 80 projection kernel
 # (chol_tiles + solve_tiles around inline-asm MFMA tuples) from 188 VGPRs to 256 + 388 B of scratch, and the kernel
@@ -53,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         return r
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])

@@ -37,6 +37,11 @@ class FomGradDesc(C.Structure):
                 ("g_ptr", c_i32p), ("g_a", c_i32p), ("g_b", c_i32p), ("g_w", c_f64p)]
 
 
+class FomBandGradDesc(C.Structure):
+    _fields_ = [("bt_ptr", c_i32p), ("bt_obs", c_i32p), ("bt_w", c_f64p),
+                ("g_ptr", c_i32p), ("g_a", c_i32p), ("g_b", c_i32p), ("g_w", c_f64p)]
+
+
 class FomSmallDesc(C.Structure):
     _fields_ = [("small_max", C.c_int32), ("npairs", C.c_int32), ("nasm", C.c_int32), ("nlev_f", C.c_int32), ("nlev_b", C.c_int32),
                 ("row_ptr", c_i32p), ("ent_col", c_i32p),
@@ -96,6 +101,7 @@ SIGNATURES = {
     "finrom_fom_set_small": (C.c_int, [C.c_void_p, C.POINTER(FomSmallDesc)]),
     "finrom_fom_set_gradient": (C.c_int, [C.c_void_p, C.POINTER(FomGradDesc)]),
     "finrom_fom_set_band": (C.c_int, [C.c_void_p, C.POINTER(FomBandDesc)]),
+    "finrom_fom_set_band_gradient": (C.c_int, [C.c_void_p, C.POINTER(FomBandGradDesc)]),
     "finrom_fom_band_validate": (C.c_int, [C.POINTER(FomBandDesc), C.c_int32, C.c_int32, C.c_int32]),
     "finrom_fom_last_path": (C.c_int, [C.c_void_p]),
     "finrom_fom_set_small_max": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -86,6 +86,7 @@ struct finrom_fom_s {
   FomDev d{};
   FomSmallDev small{};
   BandDev band{};                      // frontal band sweep (finrom_fom_set_band); band.on = 0: interpreter
+  BandGradDev band_grad{};             // adjoint gradient on the band layout (finrom_fom_set_band_gradient)
   FomDev band_asm{};                   // parameters of the band sweep's assembly pre-pass (fom_assemble_kernel)
   std::vector<void*> owned;
   Scratch xT, Gw, gradT, qtmp;
@@ -512,7 +513,7 @@ static int validate_band(const finrom_fom_band_desc* a, int n, int xdim, int n_o
       (d.n_obs > 0 && !a->obs_ptr)) return bad("table pointer (null)");
   for (int e = 0; e < 3 * G; ++e) if (a->abmap[e] < 0 || a->abmap[e] >= a->nAB) return bad("abmap");
   const int64_t nL = (int64_t)a->nfins * a->npf * a->NSF + (int64_t)a->npost * a->NSP;
-  const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n + BAND_LDS_XSIZE;
+  const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n + BAND_LDS_XSIZE + n;      // ... | y -> w | extras (LDS variant) | adjoint
   if (gsize * 512 >= (int64_t)1 << 31) { set_error("fom_set_band: workspace too long for 32-bit buffer offsets"); return FINROM_ERR_UNSUPPORTED; }
   if (a->ab_ptr[0] != 0 || a->ab_ptr[a->nAB] != a->nterms) return bad("ab_ptr");
   for (int e = 0; e < a->nAB; ++e) if (a->ab_ptr[e + 1] < a->ab_ptr[e]) return bad("ab_ptr");
@@ -616,6 +617,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   b.NSF = a->NSF; b.NSP = a->NSP; b.NX = a->NX; b.nfins = a->nfins; b.npf = a->npf; b.nif = a->nif; b.npost = a->npost;
   b.post_g0 = a->nfins * (a->npf + a->nif); b.post_e0 = a->nfins * a->npf; b.post_L0 = a->nfins * a->npf * a->NSF;
   b.offL = a->nAB; b.offLx = a->nAB + (int)nL; b.offY = a->nAB + (int)nL + a->nLx; b.offX = b.offY + n;
+  b.offV = b.offX + BAND_LDS_XSIZE;
   // records of the assembly pre-pass (fom_assemble_kernel): every value slot, so that special slots start at zero
   std::vector<int> reci((size_t)a->nAB * 8, 0);
   std::vector<double> recd((size_t)a->nAB * 5, 0.0);
@@ -661,6 +663,37 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   b.on = getenv("FINROM_BAND_TIMING") != nullptr ? 2 : 1;      // 2: block 0 reports its phase clocks in sample 0's QoI (diagnostic)
   if (getenv("FINROM_BAND_NOMEM") != nullptr) b.on |= 4;       // timing experiment (m <= 12 kernel): no L / y / w traffic, garbage results
   h->band = b;
+  return 0;
+}
+
+int finrom_fom_set_band_gradient(finrom_fom_t h, const finrom_fom_band_grad_desc* a) {
+  if (!h || !a || !a->bt_ptr || !a->g_ptr) { set_error("fom_set_band_gradient: null argument"); return FINROM_ERR_ARG; }
+  if (!h->band.on) { set_error("fom_set_band_gradient: finrom_fom_set_band has not been called"); return FINROM_ERR_ARG; }
+  const FomDev& d = h->d;
+  const int n = d.n;
+  auto bad = [&](const char* what) { set_error(std::string("fom_set_band_gradient: invalid ") + what); return FINROM_ERR_ARG; };
+  if (a->bt_ptr[0] != 0) return bad("bt_ptr");
+  for (int i = 0; i < n; ++i) if (a->bt_ptr[i + 1] < a->bt_ptr[i]) return bad("bt_ptr");
+  const int nbt = a->bt_ptr[n];
+  if (nbt > 0 && (!a->bt_obs || !a->bt_w)) return bad("table pointer (null)");
+  for (int t = 0; t < nbt; ++t) if (a->bt_obs[t] < 0 || a->bt_obs[t] >= d.n_obs) return bad("bt_obs");
+  if (a->g_ptr[0] != 0) return bad("g_ptr");
+  for (int j = 0; j < d.xdim; ++j) if (a->g_ptr[j + 1] < a->g_ptr[j]) return bad("g_ptr");
+  const int ng = a->g_ptr[d.xdim];
+  if (ng > 0 && (!a->g_a || !a->g_b || !a->g_w)) return bad("table pointer (null)");
+  for (int t = 0; t < ng; ++t) if (a->g_a[t] < 0 || a->g_a[t] >= n || a->g_b[t] < 0 || a->g_b[t] >= n) return bad("g_a / g_b");
+  BandGradDev g;
+  int rc = 0;
+  if (!rc) rc = up(h->owned, &g.bt_ptr, a->bt_ptr, n + 1);
+  if (!rc) rc = up(h->owned, &g.bt_obs, a->bt_obs, nbt);
+  if (!rc) rc = up(h->owned, &g.bt_w, a->bt_w, nbt);
+  if (!rc) rc = up(h->owned, &g.g_ptr, a->g_ptr, d.xdim + 1);
+  if (!rc) rc = up(h->owned, &g.g_a, a->g_a, ng);
+  if (!rc) rc = up(h->owned, &g.g_b, a->g_b, ng);
+  if (!rc) rc = up(h->owned, &g.g_w, a->g_w, ng);
+  if (rc) return rc;
+  g.on = 1;
+  h->band_grad = g;
   return 0;
 }
 
@@ -713,9 +746,37 @@ int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* a) {
 int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int32_t data_per_sample, int64_t S,
                         double* grad, double* J, double* qoi, int32_t* info, void* stream) {
   if (!h || S < 0 || (S > 0 && (!x || !data || !grad || !J))) { set_error("fom_gradient: bad argument"); return FINROM_ERR_ARG; }
-  if (!h->d.has_grad) { set_error("fom_gradient: finrom_fom_set_gradient has not been called"); return FINROM_ERR_ARG; }
+  if (!h->d.has_grad && !h->band_grad.on) { set_error("fom_gradient: finrom_fom_set_gradient has not been called"); return FINROM_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const FomDev& d = h->d;
+  static const bool env_no_band_grad = getenv("FINROM_NO_BAND_GRAD") != nullptr || getenv("FINROM_NO_BAND") != nullptr;
+  const bool small = h->small.small_max > 0 && S <= h->small.small_max && d.n_obs <= 64 && d.has_grad;
+  if (!small && h->band.on && h->band_grad.on && !env_no_band_grad) {
+    // the full band sweep (the factor and w stay in the workspace), then the adjoint solve and the contraction on the same layout
+    const BandDev& b = h->band;
+    h->last_path = band_path(b, false);
+    const size_t per_sample = ((size_t)b.gsize + 2 * d.xdim) * sizeof(double);
+    const int64_t limit = std::max<int64_t>(64, (int64_t)((size_t)48 << 30) / (int64_t)per_sample / 64 * 64);
+    const int64_t npieces = (S + limit - 1) / limit;
+    const int64_t chunk = npieces <= 1 ? limit : ((S + npieces - 1) / npieces + 63) / 64 * 64;
+    for (int64_t s0 = 0; s0 < S; s0 += chunk) {
+      const int64_t Sc = std::min(chunk, S - s0), nblk = (Sc + 63) / 64;
+      int rc;
+      if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+      if ((rc = h->Gw.reserve((size_t)nblk * b.gsize * 64 * sizeof(double)))) return rc;
+      if ((rc = h->gradT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+      double* q = qoi ? qoi + s0 * d.n_obs : nullptr;
+      if (!q) { if ((rc = h->qtmp.reserve((size_t)Sc * d.n_obs * sizeof(double)))) return rc; q = (double*)h->qtmp.p; }
+      if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
+      if ((rc = launch_fom_assemble(h->band_asm, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
+      if ((rc = launch_fom_band(b, (double*)h->Gw.p, nblk, Sc, q, info ? info + s0 : nullptr, st, false))) return rc;
+      if ((rc = launch_fom_band_adjoint(b, h->band_grad, (double*)h->Gw.p, nblk, Sc, q, data + (data_per_sample ? s0 * d.n_obs : 0),
+                                        data_per_sample ? d.n_obs : 0, (double*)h->gradT.p, J + s0, st))) return rc;
+      if ((rc = launch_unpack((const double*)h->gradT.p, Sc, d.xdim, d.xdim, 0, nullptr, grad + s0 * d.xdim, st))) return rc;
+    }
+    return 0;
+  }
+  if (!d.has_grad) { set_error("fom_gradient: finrom_fom_set_gradient has not been called (the band tables serve large batches only)"); return FINROM_ERR_ARG; }
   if (h->small.small_max > 0 && S <= h->small.small_max && d.n_obs <= 64) {      // small batch: value and gradient in one workgroup per sample
     int rc;
     if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;

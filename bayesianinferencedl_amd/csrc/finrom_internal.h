@@ -156,6 +156,7 @@ struct BandDev {
   int on = 0;
   int n, n_obs, xdim, gsize, nAB, nL, nLx, NSF, NSP, NX, nfins, npf, nif, npost, post_g0, post_e0, post_L0;
   int offL, offLx, offY, offX;   // offX: the extras' state of the LDS-window variant (BAND_LDS_XSIZE doubles per lane)
+  int offV;                      // adjoint right-hand side -> adjoint solution (n doubles; finrom_fom_gradient)
   const int* abmap;          // [3 G] physical value slot of each entry of a segment node
   const double* Fg; const int* act; const int* lx_ptr; const int* ent_extra; const int* ecp_ptr; const int* ecp_slot; const int* ecp_off;
   const int* schur_off; const int* iface_elim; const int* obs_ptr; const int* obs_idx; const double* obs_w; const int* perm;
@@ -165,6 +166,13 @@ struct BandDev {
   const int* qobs_ptr = nullptr; const int* qobs_idx = nullptr; const double* qobs_w = nullptr;   // post-only remainder of B_obs
   const int* row_fin = nullptr;      // [n_obs] fin whose functional belongs to the row, -1: none
 };
+struct BandGradDev {              // adjoint gradient on the band layout (finrom_fom_set_band_gradient)
+  int on = 0;
+  const int* bt_ptr = nullptr; const int* bt_obs = nullptr; const double* bt_w = nullptr;     // B_obs^T, CSR by elimination index
+  const int* g_ptr = nullptr; const int* g_a = nullptr; const int* g_b = nullptr; const double* g_w = nullptr;   // per parameter: (a, b, dA_ab/dx_j)
+};
+int launch_fom_band_adjoint(const BandDev& p, const BandGradDev& g, double* Gw, int64_t nblk, int64_t S, const double* qoi,
+                            const double* data, int64_t data_stride, double* gradT, double* J, hipStream_t st);
 constexpr int BAND_LDS_XSIZE = 256;
 bool band_supported(int NSF, int NSP, int NX);
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qoi_only);

@@ -10,7 +10,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _ffi
-from ._ffi import FomBandDesc, FomSmallDesc, DeviceBuffer, FomDesc, FomGradDesc, MlpDesc, RomDesc, check, f64, i32, lib
+from ._ffi import FomBandDesc, FomBandGradDesc, FomSmallDesc, DeviceBuffer, FomDesc, FomGradDesc, MlpDesc, RomDesc, check, f64, i32, lib
 
 
 import os as _os
@@ -243,6 +243,7 @@ class FomEngine:
             return
         check(rc, "finrom_fom_set_band")
         self.band = bp
+        self._B_band = sp.csr_matrix(np.asarray(B_obs)[:, bp.perm]) if not sp.issparse(B_obs) else sp.csr_matrix(B_obs)[:, bp.perm]
         self.band_slots = nslots            # physical value slots per sample (bench: algorithmic bytes)
         self.band_qoi_only = bool(d.qoi_FgQ) and _os.environ.get("FINROM_BAND_NO_QOI_ONLY") is None      # calls without w: QoI-only form
 
@@ -298,6 +299,14 @@ class FomEngine:
                         bt_ptr=I(Bt.indptr), bt_obs=I(Bt.indices), bt_w=D(Bt.data),
                         g_ptr=I(g_ptr), g_a=I(g_a), g_b=I(g_b), g_w=D(Wt.data))
         check(lib().finrom_fom_set_gradient(self._h, C.byref(d)), "finrom_fom_set_gradient")
+        if self.band is not None:
+            # the same tables over the band plan's elimination indices: large batches solve the adjoint on the band layout
+            bp = self.band
+            Btb = sp.csr_matrix(self._B_band.T)
+            Btb.sort_indices()
+            gb = FomBandGradDesc(bt_ptr=I(Btb.indptr), bt_obs=I(Btb.indices), bt_w=D(Btb.data), g_ptr=I(g_ptr),
+                                 g_a=I(bp.iperm[e_row[ent]]), g_b=I(bp.iperm[indices[ent]]), g_w=D(Wt.data))
+            check(lib().finrom_fom_set_band_gradient(self._h, C.byref(gb)), "finrom_fom_set_band_gradient")
         self._grad = True
 
     def gradient(self, X, data):

@@ -196,7 +196,7 @@ int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* desc);
  * Supported windows: (NSF, NSP) = (3, 6), (4, 10), (5, 14) (m = 4, 8, 12; window in registers), NX <= 4, and (6, 18), (7, 22)
  * (m = 16, 20; the post's window over four waves), NX <= 8; otherwise FINROM_ERR_UNSUPPORTED and the handle keeps using the
  * interpreter -- as it does when the load Fg is not zero on the fins' own nodes (the sweep does not carry a fin's load to its
- * interface).  finrom_fom_gradient always uses the interpreter's stored factor. */
+ * interface).  finrom_fom_gradient uses the band layout once finrom_fom_set_band_gradient has installed its tables. */
 typedef struct {
   int32_t NSF, NSP, NX;      /* window slots of a fin sweep / of the post sweep, extra slots */
   int32_t nfins, npf, nif;   /* fins, pivots per fin, interface nodes per fin */
@@ -229,6 +229,18 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* desc);
  * fins write their Schur complements to (schur_off) private -- not shared between fins, not repeated, read by one entry
  * only (the four-wave kernel sweeps the fins of a sample block on different waves).  Host only: usable without a GPU. */
 int finrom_fom_band_validate(const finrom_fom_band_desc* desc, int32_t n, int32_t xdim, int32_t n_obs);
+
+/* The adjoint gradient on the band sweep's layout (finrom_fom_gradient for batches beyond the small-batch schedule): after the
+ * full sweep the workspace holds the factor and w; A v = -B_obs^T (B_obs w - d) is solved with the stored columns (one forward
+ * substitution, one more backward sweep) and grad_j = sum dA_ab/dx_j v_a w_b is contracted there.  Tables over the band plan's
+ * ELIMINATION indices (finrom_fom_band_desc::perm):  bt_* = B_obs^T as CSR by elimination index (row e: observation indices and
+ * weights);  g_* = for every parameter j the (a, b, dA_ab/dx_j) triples.  Needs finrom_fom_set_band; without it (or for meshes
+ * without window sizes) finrom_fom_gradient keeps the interpreter's stored factor (finrom_fom_set_gradient). */
+typedef struct {
+  const int32_t* bt_ptr; const int32_t* bt_obs; const double* bt_w;     /* [n+1], [nnz(B_obs)] */
+  const int32_t* g_ptr; const int32_t* g_a; const int32_t* g_b; const double* g_w;   /* [xdim+1], [g_ptr[xdim]] */
+} finrom_fom_band_grad_desc;
+int finrom_fom_set_band_gradient(finrom_fom_t h, const finrom_fom_band_grad_desc* desc);
 
 /* ---- which schedule ran (Fin.forward has ONE solver, fom/forward_solve.py:286; this library has several schedules of the
  * same factorisation, picked by batch size and mesh) ------------------------------------------------------------------- *

@@ -121,3 +121,45 @@ def test_dispatch_by_batch_size(spaces, m, small_path, small_max):
     # two schedules of the same factorisation (other elimination order, other summation order): round-off times the operator's
     # condition number (kappa in [0.1, 10]: 2e-12 measured at m = 20), an order below the parity tolerance
     assert _rel(a["qoi"], b["qoi"][:small_max]) < 1e-11
+
+
+@pytest.mark.parametrize("m", [12, 16, 20])
+def test_adjoint_gradient_on_the_band_layout(problems, spaces, m):
+    """finrom_fom_gradient for batches beyond the small-batch schedule (Fin.gradient, fom/forward_solve.py:293-322): the full
+    band sweep leaves the factor and w in the workspace, fom_band_adjoint_kernel solves the adjoint with the stored columns
+    (forward substitution + one more backward sweep) and contracts the gradient there -- against the oracle, against the
+    interpreter's stored-factor path on every sample, with shared and per-sample data, batch tail, a flagged sample."""
+    prob, V = problems(m), spaces(m)
+    fo = O.FinOracle(prob)
+    rng = np.random.default_rng(50 + m)
+    S = 200                                               # 3 blocks + a tail of 8 lanes
+    fin, fin_i = _throughput_engines(V)
+    data = rng.uniform(0.1, 0.6, 9)
+    for params, dim in (("field", prob.n), ("nine", 9), ("five", 5)):
+        X = np.exp(0.3 * rng.standard_normal((S, dim))) if params == "field" else rng.uniform(0.3, 5.0, (S, dim))
+        kw = dict(params=None if params == "field" else params)
+        res = fin.gradient_batch(X, data, **kw)
+        assert fin._engine(params).last_path() == BAND_PATH[m]
+        ref = fin_i.gradient_batch(X, data, **kw)
+        assert fin_i._engine(params).last_path() == "interpreter"
+        assert (res["info"] == 0).all()
+        assert _rel(res["grad"], ref["grad"]) < 1e-9 and np.max(np.abs(res["J"] - ref["J"]) / ref["J"]) < 1e-10
+        lift = {"field": lambda x: x, "nine": fo.nine_param_to_function, "five": fo.five_param_to_function}[params]
+        ops = V.operators()
+        chain = {"field": None, "nine": ops.N9, "five": ops.N9 @ ops.E59}[params]
+        for s in (0, 63, 64, S - 1):
+            g = fo.gradient(lift(X[s]), data)
+            g = g if chain is None else g @ chain
+            assert np.linalg.norm(res["grad"][s] - g) < 1e-9 * np.linalg.norm(g), (params, s)
+            J = 0.5 * np.sum((fo.qoi_operator(fo.forward(lift(X[s]))) - data) ** 2)
+            assert abs(res["J"][s] - J) < 1e-10 * J
+    # per-sample data and a sample whose operator is indefinite
+    X = rng.uniform(0.3, 5.0, (S, 9))
+    X[77, 2] = -4.0
+    D2 = rng.uniform(0.1, 0.6, (S, 9))
+    res = fin.gradient_batch(X, D2, params="nine")
+    assert fin._engine("nine").last_path() == BAND_PATH[m]
+    assert np.nonzero(res["info"])[0].tolist() == [77] and np.isnan(res["grad"][77]).all()
+    good = np.setdiff1d(np.arange(S), [77])
+    ref = fin_i.gradient_batch(X[good], D2[good], params="nine")
+    assert _rel(res["grad"][good], ref["grad"]) < 1e-9
