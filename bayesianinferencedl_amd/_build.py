@@ -13,7 +13,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfinrom_hip.so")
 SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "finrom_internal.h"), os.path.join(CSRC, "rom_proj_device.h"), os.path.join(CSRC, "fom_band_device.h"), os.path.join(ROOT, "include", "finrom.h")]
-FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + \
+    os.environ.get("FINROM_EXTRA_FLAGS", "").split()      # (A/B builds of tuning constants, e.g. -DADJ_RING=2)
 # rom_proj_single.hip is built at -O2: at -O3 hipcc's extra passes inflate the register pressure of the r = 80 projection kernel
 # (chol_tiles + solve_tiles around inline-asm MFMA tuples) from 188 VGPRs to 256 + 388 B of scratch, and the kernel
 # must stay at <= 192 to share SIMDs with the FOM interpreter.  The MFMA main loop is inline asm either way.

@@ -12,13 +12,15 @@ namespace {
 // more backward sweep (band_bsweep on the region offV) -- and grad_j = sum dA_ab/dx_j v_a w_b is contracted from the two vectors
 // in the workspace.  No window of the matrix is needed any more (only the right-hand-side window: NS doubles), so one wave per
 // 64 samples serves every mesh, m = 16 / 20 included.  Traffic per sample ~ 2 nL + 6 n + 2 nnz(dA/dx) doubles.
-template <int NS, bool POST, int NXM>
+template <int NS, bool POST, int NXM, int RBX = 0>
 __device__ __forceinline__ void band_fsub(const BandDev& p, const Io& io, const PostTables& T, const int* __restrict__ iface, int e0,
                                           int npiv, int ntot, int L0, int offR, double (&xy)[NXM]) {
   double yw[NS];
   static_for<0, NS>([&](auto i) { yw[decltype(i)::value] = 0.0; });
   // the column of pivot v (l_1 .. l_B, 1/L_vv) and its right-hand side are requested RB pivots ahead (ring slots compile-time)
-  constexpr int RB = NS % 7 == 0 ? 7 : NS % 5 == 0 ? 5 : NS % 3 == 0 ? 3 : NS % 2 == 0 ? 2 : NS;
+  // (RBX: an explicit, shallower ring -- this kernel has no matrix window, so several waves share a SIMD and hide each other's
+  // latency: a deep ring per wave would only cost it that occupancy)
+  constexpr int RB = RBX > 0 ? RBX : NS % 7 == 0 ? 7 : NS % 5 == 0 ? 5 : NS % 3 == 0 ? 3 : NS % 2 == 0 ? 2 : NS;
   constexpr int U = NS / gcd_c(NS, RB) * RB;
   double lb[RB][NS + 1];
   auto request = [&](auto rc, int nx) {
@@ -73,6 +75,9 @@ __device__ __forceinline__ void band_fsub(const BandDev& p, const Io& io, const 
   }
 }
 
+#ifndef ADJ_RING
+#define ADJ_RING 3
+#endif
 template <int NSF, int NSP, int NXM>
 __global__ __launch_bounds__(64) void fom_band_adjoint_kernel(BandDev p, const int* __restrict__ act, const int* __restrict__ lx_ptr,
                                                               const int* __restrict__ ent_extra, const int* __restrict__ iface_elim,
@@ -106,12 +111,13 @@ __global__ __launch_bounds__(64) void fom_band_adjoint_kernel(BandDev p, const i
   }
   double xy[NXM];
   static_for<0, NXM>([&](auto i) { xy[decltype(i)::value] = 0.0; });
+  constexpr int RBF = ADJ_RING, RBP = ADJ_RING;          // columns in flight per wave and sweep
   for (int f = 0; f < p.nfins; ++f)
-    band_fsub<NSF, false, NXM>(p, io, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF, p.offV, xy);
-  band_fsub<NSP, true, NXM>(p, io, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0, p.offV, xy);
-  band_bsweep<NSP, true, NXM>(p, io, wx, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0, p.offV);
+    band_fsub<NSF, false, NXM, RBF>(p, io, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF, p.offV, xy);
+  band_fsub<NSP, true, NXM, RBP>(p, io, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0, p.offV, xy);
+  band_bsweep<NSP, true, NXM, RBP>(p, io, wx, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0, p.offV);
   for (int f = 0; f < p.nfins; ++f)
-    band_bsweep<NSF, false, NXM>(p, io, wx, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF, p.offV);
+    band_bsweep<NSF, false, NXM, RBF>(p, io, wx, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF, p.offV);
   // grad_j = sum dA_ab/dx_j v_a w_b, loads batched by 4 pairs (a failed factorisation left NaN in w: it propagates)
   for (int j = 0; j < p.xdim; ++j) {
     double g0 = 0.0, g1 = 0.0;
