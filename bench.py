@@ -662,3 +662,44 @@ def measured_traffic(kernel, workload_key):
         except Exception:
             continue
     return None
+
+
+def cpu_baseline(args, phi, Xs, res, pairs):
+    """The oracle's one-sample-at-a-time loop (what the reference does, minus FEniCS form
+    assembly overhead) on ONE host core, on the first `cpu_samples` inputs of the GPU batch."""
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:
+        limiter = None
+    from oracle import fin_oracle as O
+    prob = O.FinProblem(args.m)
+    fo = O.FinOracle(prob)
+    ro = O.AffineROMOracle(prob, phi)
+    lift = {"five": fo.five_param_to_function, "nine": fo.nine_param_to_function, "field": lambda x: x}[args.params]
+    budget_s = 25.0
+    t0 = time.perf_counter()
+    done = 0
+    q = np.zeros((len(Xs), 9)); qr = np.zeros((len(Xs), 9))
+    for i in range(len(Xs)):
+        k = lift(Xs[i])
+        w = fo.forward(k)
+        w_r = ro.forward_reduced(k)
+        q[i] = fo.qoi_operator(w); qr[i] = ro.qoi_reduced(w_r)
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
+    gq = res["qoi"][:done].cpu().numpy(); gqr = res["qoi_r"][:done].cpu().numpy()
+    dev = float(max(np.max(np.linalg.norm(gq - q[:done], axis=1) / np.linalg.norm(q[:done], axis=1)),
+                    np.max(np.linalg.norm(gqr - qr[:done], axis=1) / np.linalg.norm(qr[:done], axis=1))))
+    return {"value": done / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {done} samples of the GPU batch, oracle/fin_oracle.py loop (SciPy SuperLU FOM + NumPy LSPG ROM), "
+                      f"1 thread; max rel QoI deviation GPU vs oracle on them = {dev:.2e}"}
+
+
+if __name__ == "__main__":
+    main()
