@@ -18,7 +18,7 @@ echo "[1] headline kernel stats"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/overlapped -o run -- python $B > $out/bench_overlapped.log 2>&1 || exit 1
 FINROM_NO_OVERLAP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $out/serial -o run -- python $B > $out/bench_serial.log 2>&1 || exit 1
 pmc_pass() {   # <subdir> <bench args...>: HBM / L2 / SQ counter groups, halves in turn
-  sub=$1; shift
+  sub=$1; shift; mkdir -p $out/$sub
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
              "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_VMEM_RD"; do
     d=$out/$sub/pmc_$(echo $grp | tr ' ' '_' | cut -c1-60)
