@@ -1303,13 +1303,11 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   // every sweep wave, and since the projection hides its non-MFMA work behind its own MFMAs a lone wave per SIMD is efficient:
   // measured 26.3 ms side by side against 29.1 ms in turn per 100k samples (r = 80).
   static const bool env_no_overlap = getenv("FINROM_NO_OVERLAP") != nullptr;      // (read once, not per call)
-  static const bool env_force_overlap = getenv("FINROM_FORCE_OVERLAP") != nullptr;
-  // The four-wave band sweep (m = 16, 20) takes a whole CU's LDS (157 KB per workgroup) and the wide-basis projection 43 KB per
-  // workgroup: the two kernels cannot share a CU, side by side they only took turns at the hardware's discretion (r = 200, 125k
-  // samples: step 420 ms against 428 in turn, the sweep event-timed at 203 ms instead of its 21 ms, the sub-fin averages starved
-  // ninefold).  Those sizes run in turn -- same throughput, meaningful kernel timings; FINROM_FORCE_OVERLAP=1 for A/B.
-  const bool lds_exclusive = fom->band.on && fom->band.NSP > 14 && !env_force_overlap;
-  const bool overlap = g_overlap && !env_no_overlap && !lds_exclusive;
+  // (The four-wave band sweep of m = 16, 20 takes a whole CU's LDS -- 157 KB per workgroup -- and the wide-basis projection 43 KB
+  // per workgroup: the two kernels cannot share a CU, side by side they take turns CU by CU at the dispatcher's discretion.  That
+  // still beats running them in turn by 1-5 % (r = 200: 68.6 against 72.0 ms per 20k samples, 420 against 425 ms per 125k), so
+  // those sizes fork too; their event-timed kernel durations then include waiting for CUs -- FINROM_NO_OVERLAP=1 gives clean ones.)
+  const bool overlap = g_overlap && !env_no_overlap;
   hipStream_t side = overlap ? rom->side : st;
   const bool tracing = trace_prefix() != nullptr;
   if (tracing) {
