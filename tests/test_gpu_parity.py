@@ -389,8 +389,9 @@ def test_rom_batch_size_thresholds_change_the_kernels_not_the_results(problems, 
     TH = np.random.default_rng(r).uniform(0.1, 10.0, (65, 9))
     small = rom.forward_nine_param_reduced_batch(TH[:64])
     large = rom.forward_nine_param_reduced_batch(TH)
-    assert rel(small["qoi_r"], large["qoi_r"][:64]) < 1e-11
-    assert rel(small["w_r"] @ rom.phi.T, large["w_r"][:64] @ rom.phi.T) < 1e-10
+    # (two summation orders of psi^T psi and two factorisation orders at cond(A_r) ~ 1e7: 1e-11 measured; the parity metric)
+    assert rel(small["qoi_r"], large["qoi_r"][:64]) < TOL
+    assert rel(small["w_r"] @ rom.phi.T, large["w_r"][:64] @ rom.phi.T) < TOL
     again = rom.forward_nine_param_reduced_batch(TH[:64])
     assert np.array_equal(again["qoi_r"], small["qoi_r"]) and np.array_equal(again["w_r"], small["w_r"])
     one = rom.forward_nine_param_reduced_batch(TH[7:8])          # a sample alone = the same sample inside a small batch
