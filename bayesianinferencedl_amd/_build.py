@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfinrom_hip.so")
-SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip"]
+SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "finrom_internal.h"), os.path.join(CSRC, "rom_proj_device.h"), os.path.join(CSRC, "fom_band_device.h"), os.path.join(ROOT, "include", "finrom.h")]
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + \
     os.environ.get("FINROM_EXTRA_FLAGS", "").split()      # (A/B builds of tuning constants, e.g. -DADJ_RING=2)
@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     return LIB
 
 

@@ -125,6 +125,10 @@ SIGNATURES = {
     "finrom_romml_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 6),
     "finrom_solve_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 8),
     "finrom_sub": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "finrom_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "finrom_comm_init": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "finrom_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "finrom_comm_destroy": (C.c_int, [C.c_void_p]),
 }
 
 ABI_VERSION = 9

@@ -29,3 +29,43 @@ def gather_rows(local, world: int, total: int | None = None, force: bool = False
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous())
     return out if total is None else out[:total]
+
+
+class FinromComm:
+    """The same gather through the C ABI (finrom_comm_* in include/finrom.h): RCCL loaded by the library itself, no
+    torch.distributed.  rank 0: ``uid = FinromComm.unique_id()`` and hand the bytes to the other ranks; every rank (its device
+    current): ``comm = FinromComm(rank, world, uid)``; ``comm.gather(ptr, count, out_ptr)`` all-gathers `count` doubles per rank
+    between DEVICE buffers (DeviceBuffer.ptr / tensor.data_ptr())."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from ._ffi import check, lib
+        buf = C.create_string_buffer(128)
+        check(lib().finrom_comm_unique_id(buf), "finrom_comm_unique_id")
+        return buf.raw
+
+    def __init__(self, rank: int, world: int, uid: bytes):
+        import ctypes as C
+        from ._ffi import check, lib
+        if len(uid) != 128:
+            raise ValueError("unique id must be FINROM_COMM_ID_BYTES = 128 bytes")
+        self.rank, self.world = rank, world
+        self._h = C.c_void_p()
+        check(lib().finrom_comm_init(C.byref(self._h), rank, world, C.create_string_buffer(uid, 128)), "finrom_comm_init")
+
+    def gather(self, send_ptr, count, recv_ptr, stream=None):
+        from ._ffi import check, lib
+        check(lib().finrom_gather(self._h, send_ptr, int(count), recv_ptr, stream), "finrom_gather")
+
+    def close(self):
+        from ._ffi import lib
+        if getattr(self, "_h", None):
+            lib().finrom_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

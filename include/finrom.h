@@ -378,6 +378,23 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop,
                        double* qoi, double* qoi_r, double* err,
                        double* w, double* w_r, double* theta, int32_t* info, void* stream);
 
+/* ---- the gather at the end for callers without torch.distributed ------------------------------------------------ *
+ * The path shards by samples with no data-path collective; the one exchange is an all-gather of per-sample rows (QoI pairs,
+ * 144 B per sample) when every rank has finished its shard -- the reference's loop (deep_learning/generate_fin_dataset.py:83-100)
+ * run per rank, results collected once.  RCCL over xGMI, loaded with dlopen at the first call (no link-time dependency; a process
+ * that already holds PyTorch's RCCL shares it).  Protocol: rank 0 calls finrom_comm_unique_id and hands the FINROM_COMM_ID_BYTES
+ * bytes to the other ranks by whatever channel the launcher offers (file, socket, MPI, environment); every rank, with ITS device
+ * current (finrom_set_device), calls finrom_comm_init; finrom_gather(send [count], recv [nranks x count]) is an all-gather of
+ * `count` doubles per rank on DEVICE buffers, asynchronous on `stream`, rank r's block at recv + r * count.
+ * One process per GPU (RCCL rejects two ranks on one device).  bench.py and bayesianinferencedl_amd/distributed.py keep using
+ * torch.distributed when torch is the launcher; both routes end in ncclAllGather. */
+#define FINROM_COMM_ID_BYTES 128
+typedef struct finrom_comm_s* finrom_comm_t;
+int finrom_comm_unique_id(void* id_out);
+int finrom_comm_init(finrom_comm_t* out, int32_t rank, int32_t nranks, const void* id);
+int finrom_gather(finrom_comm_t comm, const double* send, int64_t count, double* recv, void* stream);
+int finrom_comm_destroy(finrom_comm_t comm);
+
 /* ---- elementwise helper: err = qoi - qoi_r (generate_fin_dataset.py:99) -------------- */
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream);
 

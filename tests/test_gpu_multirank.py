@@ -58,3 +58,26 @@ def test_one_rank_rccl_process_group_and_device_gather():
     # and without the launcher: bench.py --force-pg makes its own one-rank rendezvous
     alone = _bench(argv)
     assert alone["process_group"]["backend"] == "nccl" and alone["gathered_sha256"] == plain["gathered_sha256"]
+
+
+def test_c_abi_gather_one_rank():
+    """finrom_comm_* (the gather at the end for callers without torch): RCCL loaded by the library with dlopen, a one-rank
+    communicator on cuda:0, an all-gather between device buffers allocated through the C ABI.  (Two ranks cannot share the one
+    GPU of this box -- RCCL rejects duplicate devices -- so the N > 1 form of this route is exercised by construction only:
+    it is the same ncclAllGather call with nranks > 1.)"""
+    import numpy as np
+    from bayesianinferencedl_amd import _ffi
+    from bayesianinferencedl_amd.distributed import FinromComm
+    _ffi.check(_ffi.lib().finrom_set_device(0))
+    uid = FinromComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = FinromComm(0, 1, uid)
+    x = np.random.default_rng(0).standard_normal((1000, 18))
+    src = _ffi.DeviceBuffer.from_numpy(x)
+    dst = _ffi.DeviceBuffer(x.nbytes); dst.zero()
+    comm.gather(src.ptr, x.size, dst.ptr)
+    _ffi.check(_ffi.lib().finrom_stream_sync(None))
+    assert np.array_equal(dst.to_numpy(x.shape), x)
+    comm.close()
+    h = __import__("ctypes").c_void_p()
+    assert _ffi.lib().finrom_comm_init(__import__("ctypes").byref(h), 2, 2, uid) == -1      # rank out of range
