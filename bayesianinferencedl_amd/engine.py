@@ -35,12 +35,26 @@ def _is_torch(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
 
+class DeviceArray:
+    """A [S, d] fp64 array that already lives on the device in a library-owned buffer: the output of one call handed to the
+    next without a round trip through the host (sub-fin averages -> reduced solve for NumPy callers)."""
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, tuple(shape)
+
+
 class _Batch:
     """Uniform view of a [S, d] fp64 batch living on the device."""
 
     def __init__(self, x, d):
         self.torch = _is_torch(x)
-        if self.torch:
+        if isinstance(x, DeviceArray):
+            assert x.shape[-1] == d, (x.shape, d)
+            self.S = int(np.prod(x.shape[:-1]))
+            self.keep = x.buf
+            self.ptr = x.buf.ptr
+            self.stream = None
+        elif self.torch:
             import torch
             if not x.is_cuda or x.dtype != torch.float64:
                 raise TypeError("torch inputs must be float64 CUDA tensors")
@@ -446,6 +460,15 @@ class SubfinAverager:
         th, tp = b.new((b.S, self.P))
         check(lib().finrom_subfin_avg(self._S.ptr, self.P, self.n, b.ptr, b.S, tp, b.stream), "finrom_subfin_avg")
         return b.out(th, (b.S, self.P))
+
+    def on_device(self, K):
+        """NumPy K [S, n] -> theta as a DeviceArray (no copy back): the next library call consumes it in place."""
+        b = _Batch(K, self.n)
+        buf = DeviceBuffer(max(b.S * self.P * 8, 8))
+        check(lib().finrom_subfin_avg(self._S.ptr, self.P, self.n, b.ptr, b.S, buf.ptr, None), "finrom_subfin_avg")
+        out = DeviceArray(buf, (b.S, self.P))
+        out._src = b.keep                                  # (the input's staging buffer lives until theta has been consumed)
+        return out
 
 
 class FieldSampler:

@@ -112,12 +112,15 @@ class AffineROMFin:
         return np.stack([A.toarray() for A in self._A_sub])
 
     # ---- batched extensions (new, additive) ---------------------------------------------
-    _HOST_AVG_MAX = 16      # NumPy batches up to this size: theta = S k on the host (a [9 x n] product, microseconds) instead
-                            # of a device round trip (two copies + a launch, ~0.15 ms) -- the one-sample MAP / HMC call pattern
-
     def subfin_avg_batch(self, K):
-        if isinstance(K, np.ndarray) and K.ndim == 2 and K.shape[0] <= self._HOST_AVG_MAX:
-            return np.ascontiguousarray(K, dtype=np.float64) @ self.ops.S.T
+        """theta = S k on the device (finrom_subfin_avg), NumPy in -> NumPy out / torch in -> torch out."""
+        return self._avg(K)
+
+    def _theta_dev(self, K):
+        """theta for the NEXT library call: NumPy fields are averaged on the device and stay there (a DeviceArray the reduced
+        solve reads in place: one copy in, one copy of the results back -- the one-sample call pattern pays for every round trip)."""
+        if isinstance(K, np.ndarray):
+            return self._avg.on_device(np.ascontiguousarray(K, dtype=np.float64).reshape(-1, self.n))
         return self._avg(K)
 
     def forward_nine_param_reduced_batch(self, theta, want_state=False, want_w=True):
@@ -126,14 +129,14 @@ class AffineROMFin:
 
     def forward_reduced_batch(self, K, want_state=False, want_w=True):
         """K [S, n] nodal fields -> theta = S k on the device -> reduced solve."""
-        return self._rom.solve(self.subfin_avg_batch(K), want_state=want_state, want_w=want_w)
+        return self._rom.solve(self._theta_dev(K), want_state=want_state, want_w=want_w)
 
     def forward_batch(self, K, want_w=True):
         """'Averaged FOM' (:237-258) for a batch of nodal fields."""
         if self._fom is None:
             ops = self.ops
             self._fom = FomEngine(self._plan, ops.robin_vals, sp.csr_matrix(ops.sub_vals.T), ops.F, self.B_obs, ops=ops)
-        return self._fom.solve(self.subfin_avg_batch(K), want_w=want_w)
+        return self._fom.solve(self._theta_dev(K), want_w=want_w)
 
     def _ensure_gradient(self):
         """One-time: G_pi = (A_p Phi)^T (A_i Phi) for the region pairs that share nodes (finrom_rom_set_gradient)."""
@@ -154,7 +157,7 @@ class AffineROMFin:
         dict(J [S], g_theta [S, 9], w_r, qoi_r, info);  dJ_dk = g_theta @ dsigma_dk."""
         self._ensure_gradient()
         data = self.data if data is None else data
-        th = self.subfin_avg_batch(K) if theta is None else theta
+        th = self._theta_dev(K) if theta is None else theta
         res = self._rom.grad(th, data)
         res["g_theta"] = res.pop("g")
         return res
