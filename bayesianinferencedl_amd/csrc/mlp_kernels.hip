@@ -4,8 +4,8 @@
 //     y0 = W0^T x + b0;   y_{i+1} = y_i + W_i^T elu(s_i y_i + t_i) + b_i  (i < L);   out = W_h^T elu(s_h y_L + t_h) + b_h
 // (batch normalisation in inference form: s = gamma / sqrt(var + eps), t = beta - mean s; the first BN-activation-Dense triple of
 // the reference's residual_unit is dead code, :150-158).
-// One workgroup per sample (the call pattern is S = 1 .. a few chains: latency, not throughput): x in LDS, the first layer
-// split over 5 threads per hidden unit, the 50 x 50 layers one thread per output.  Forward keeps the pre-activations
+// One workgroup of 1024 threads per sample (the call pattern is S = 1 .. a few chains: latency, not throughput): x in LDS, the
+// first layer split over 16 threads per hidden unit, the 50 x 50 layers one thread per output.  Forward keeps the pre-activations
 // ("tape", (L + 1) x n_w floats per sample) for the backward kernel, which runs after the ROM adjoint (its upstream is the
 // residual data - (qoi_r + e_NN)) and also adds the ROM part g_theta^T S, so that the final gradient is written once.
 #include "finrom_internal.h"
@@ -16,12 +16,15 @@ __device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z)
 __device__ __forceinline__ float elu_grad_f(float z) { return z > 0.f ? 1.f : expf(z); }
 
 constexpr int MLP_MAX_W = 64;        // hidden width (reference: 50 / 100 -> 64 covers load_bn_model's models; checked at create)
-constexpr int MLP_PARTS = 4;         // threads per hidden unit in the first layer (256 threads = 64 units x 4 parts)
+constexpr int MLP_PARTS = 16;        // threads per hidden unit in the first layer (1024 threads = 64 units x 16 parts: the layer is
+                                     // 1597 x 50 dependent-load multiply-adds per sample and the call is latency-bound -- 100 rows
+                                     // per thread, 32 loads in flight, instead of 400 rows with 4 parts: 28 -> ~10 us)
+constexpr int MLP_THREADS = 64 * MLP_PARTS;
 
 // e_out[s][o] (double) = network output; data_shift[s][o] = data[o] - e_out (what the ROM adjoint is run against)
 // (Sop, P, theta_out: when given, the sub-fin averages theta = S k of the same field (fom/forward_solve.py:466-480) are formed here
 // in fp64 while k is being read anyway -- one launch less in the one-sample call chain of finrom_romml_grad)
-__global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev m, const double* __restrict__ k, int64_t S,
+__global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, const double* __restrict__ k, int64_t S,
                                                           const double* __restrict__ data, int64_t data_stride,
                                                           float* __restrict__ tape, double* __restrict__ e_out,
                                                           double* __restrict__ data_shift, const double* __restrict__ Sop, int P,
@@ -29,13 +32,13 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev m, const double
   extern __shared__ float xs[];                        // [n_in] input, then scratch
   __shared__ float part[MLP_PARTS][MLP_MAX_W];
   __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
-  __shared__ double tred[4][16];
+  __shared__ double tred[MLP_PARTS][16];
   const int64_t s = blockIdx.x;
   const int tid = threadIdx.x, nw = m.n_w;
   double th[16];
 #pragma unroll
   for (int p = 0; p < 16; ++p) th[p] = 0.0;
-  for (int i = tid; i < m.n_in; i += 256) {
+  for (int i = tid; i < m.n_in; i += MLP_THREADS) {
     const double kv = k[s * m.n_in + i];
     xs[i] = (float)kv;
     if (theta_out != nullptr) {
@@ -52,7 +55,12 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev m, const double
     }
   }
   __syncthreads();
-  if (theta_out != nullptr && tid < P) theta_out[s * P + tid] = (tred[0][tid] + tred[1][tid]) + (tred[2][tid] + tred[3][tid]);
+  if (theta_out != nullptr && tid < P) {               // the waves' partial sums in a fixed order
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < MLP_PARTS; ++w) t += tred[w][tid];
+    theta_out[s * P + tid] = t;
+  }
   {                                                   // y0 = W0^T x + b0: unit j = tid % 64, part p = tid / 64 of the rows
     const int j = tid & 63, p = tid >> 6;
     float acc = 0.f;
@@ -73,7 +81,12 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev m, const double
     part[p][j] = acc;
   }
   __syncthreads();
-  if (tid < nw) y[tid] = m.b0[tid] + ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+  if (tid < nw) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < MLP_PARTS; ++w) t += part[w][tid];
+    y[tid] = m.b0[tid] + t;
+  }
   __syncthreads();
   float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
   for (int l = 0; l <= m.n_layers; ++l) {              // l == n_layers: the head
@@ -99,7 +112,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(MlpDev m, const double
 
 // grad[s][i] = sum_p g_theta[s][p] Sop[p][i]  -  sum_j g0[j] W0[i][j],  g0 = d(1/2 |r|^2)/d(y0) with upstream r = data - (qoi_r + e)
 // loss[s] = 1/2 |r|^2 is recomputed here from the same residual (the ROM kernel's J is that of the shifted data: the same number)
-__global__ __launch_bounds__(256) void mlp_backward_kernel(MlpDev m, int64_t S, const float* __restrict__ tape,
+__global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int64_t S, const float* __restrict__ tape,
                                                            const double* __restrict__ data, int64_t data_stride,
                                                            const double* __restrict__ qoi_r, const double* __restrict__ e_nn,
                                                            const double* __restrict__ g_theta, const double* __restrict__ Sop,
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(256) void mlp_backward_kernel(MlpDev m, int64_t S, 
     if (tid < nw) g[tid] = gn[tid];
     __syncthreads();
   }
-  for (int i = tid; i < m.n_in; i += 256) {
+  for (int i = tid; i < m.n_in; i += MLP_THREADS) {
     float acc = 0.f;
     {
       const float* __restrict__ wrow = m.W0 + (int64_t)i * nw;
@@ -160,7 +173,7 @@ int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double
   if (S == 0) return 0;
   if (theta_out != nullptr && (P < 1 || P > 16)) { set_error("mlp_forward: at most 16 sub-fin averages"); return FINROM_ERR_UNSUPPORTED; }
   ScopedKernelTimer t(K_MISC, st);
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)S), dim3(256), (size_t)m.n_in * sizeof(float), st, m, k, S, data, data_stride,
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3((unsigned)S), dim3(MLP_THREADS), (size_t)m.n_in * sizeof(float), st, m, k, S, data, data_stride,
                      tape, e_out, data_shift, Sop, P, theta_out);
   FR_HIP(hipGetLastError());
   return 0;
@@ -170,7 +183,7 @@ int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const dou
                         const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_MISC, st);
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3((unsigned)S), dim3(256), 0, st, m, S, tape, data, data_stride, qoi_r, e_nn, g_theta,
+  hipLaunchKernelGGL(mlp_backward_kernel, dim3((unsigned)S), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride, qoi_r, e_nn, g_theta,
                      Sop, P, grad);
   FR_HIP(hipGetLastError());
   return 0;

@@ -766,56 +766,65 @@ __global__ __launch_bounds__(64) void rom_grad_contract_kernel(RomDev p, int64_t
 // The same contraction for a handful of samples (one-sample call patterns): latency, not throughput -- ROM_GRAD_SMALL_NG
 // workgroups per sample, each walks its share of the blocks G_pi as flat arrays (64 consecutive entries per step, 16 steps in
 // flight) with v_r, w_r in LDS; the last workgroup to arrive (ticket) adds the partial sums in a fixed order.
-__global__ __launch_bounds__(64) void rom_grad_contract_small_kernel(RomDev p, int64_t S, RomGradArgs ga) {
+__global__ __launch_bounds__(256) void rom_grad_contract_small_kernel(RomDev p, int64_t S, RomGradArgs ga) {
   extern __shared__ __attribute__((aligned(16))) double cs[];
-  const int r = p.r, R = p.rp, lane = threadIdx.x, grp = blockIdx.y, NG = gridDim.y;
+  __shared__ double wsum[4];
+  __shared__ double gacc[32];
+  const int r = p.r, R = p.rp, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = blockIdx.y, NG = gridDim.y;
   const int64_t s = blockIdx.x;
   double* vs = cs; double* ws = cs + R;
-  for (int t = lane; t < 2 * R; t += 64) cs[t] = ga.vw[s * (int64_t)(2 * R) + t];
+  for (int t = tid; t < 2 * R; t += 256) cs[t] = ga.vw[s * (int64_t)(2 * R) + t];
+  if (tid < 32) gacc[tid] = 0.0;
   __syncthreads();
-  double g = 0.0;
+  // (four waves per workgroup: a block G_pi is r^2 = 6561 dependent-free loads at r = 81 -- 26 per thread, 16 in flight, instead
+  // of 103 per lane with one wave: the call is latency-bound)
   for (int pi = grp; pi < ga.npairs; pi += NG) {
     const double* __restrict__ G = ga.Gt + (int64_t)pi * r * r;      // G[c r + row]
     const int n = r * r;
     double part = 0.0;
-    int c2 = 0, row = lane;                              // entry base + lane = c2 r + row
+    int c2 = 0, row = tid;                               // entry base + tid = c2 r + row
     while (row >= r) { row -= r; ++c2; }
-    for (int base = 0; base < n; base += 64 * 16) {
+    for (int base = 0; base < n; base += 256 * 16) {
       double gv[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { const int idx = base + u * 64 + lane; gv[u] = idx < n ? G[idx] : 0.0; }
+      for (int u = 0; u < 16; ++u) { const int idx = base + u * 256 + tid; gv[u] = idx < n ? G[idx] : 0.0; }
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        if (base + u * 64 + lane < n) part = fma(gv[u] * vs[row], ws[c2], part);
-        row += 64;
-        if (row >= r) { row -= r; ++c2; }
-        if (row >= r) { row -= r; ++c2; }
+        if (base + u * 256 + tid < n) part = fma(gv[u] * vs[row], ws[c2], part);
+        row += 256;
+        while (row >= r) { row -= r; ++c2; }
       }
     }
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-    const int pp = ga.pair_p[pi];
-    const double thp = pp == 0 ? 1.0 : ga.theta[s * p.P + pp - 1];
-    if (lane == ga.pair_i[pi]) g = fma(thp, part, g);
+    if (lane == 0) wsum[wv] = part;
+    __syncthreads();
+    if (tid == 0) {
+      const int pp = ga.pair_p[pi];
+      const double thp = pp == 0 ? 1.0 : ga.theta[s * p.P + pp - 1];
+      gacc[ga.pair_i[pi]] = fma(thp, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), gacc[ga.pair_i[pi]]);
+    }
+    __syncthreads();
   }
-  if (lane < 32) ga.gpart[(s * NG + grp) * 32 + lane] = g;
+  if (tid < 32) ga.gpart[(s * NG + grp) * 32 + tid] = gacc[tid];
   __threadfence();
-  int last = 0;
-  if (lane == 0) last = atomicAdd(&ga.ticket[s], 1) == NG - 1;
-  last = __shfl(last, 0);
-  if (!last) return;
+  __syncthreads();
+  __shared__ int last_s;
+  if (tid == 0) last_s = atomicAdd(&ga.ticket[s], 1) == NG - 1;
+  __syncthreads();
+  if (!last_s) return;
   __threadfence();                                       // the other workgroups' partial sums are visible
-  if (lane < p.P) {
+  if (tid < p.P) {
     double t = 0.0;
-    for (int w = 0; w < NG; ++w) t += ga.gpart[(s * NG + w) * 32 + lane];
-    ga.g[s * p.P + lane] = t;
+    for (int w = 0; w < NG; ++w) t += ga.gpart[(s * NG + w) * 32 + tid];
+    ga.g[s * p.P + tid] = t;
   }
-  if (lane == 0) ga.ticket[s] = 0;                       // ready for the next call
+  if (tid == 0) ga.ticket[s] = 0;                        // ready for the next call
 }
 
 int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  hipLaunchKernelGGL(rom_grad_contract_small_kernel, dim3((unsigned)S, ROM_GRAD_SMALL_NG), dim3(64), (size_t)2 * p.rp * sizeof(double), st, p, S, ga);
+  hipLaunchKernelGGL(rom_grad_contract_small_kernel, dim3((unsigned)S, ROM_GRAD_SMALL_NG), dim3(256), (size_t)2 * p.rp * sizeof(double), st, p, S, ga);
   FR_HIP(hipGetLastError());
   return 0;
 }
