@@ -95,9 +95,17 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, cons
     __syncthreads();
     if (l < m.n_layers) {
       const float* W = m.W + (int64_t)l * nw * nw;
-      if (tid < nw) {
-        float acc = m.b[l * nw + tid];
-        for (int i = 0; i < nw; ++i) acc = fmaf(a[i], W[i * nw + tid], acc);
+      if (tid < nw) {                                 // (weights requested 16 at a time: every load waited for on its own is a
+        float acc = m.b[l * nw + tid];                 //  trip to L2 on the critical path of a one-sample call)
+        int i = 0;
+        for (; i + 16 <= nw; i += 16) {
+          float wv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) wv[u] = W[(i + u) * nw + tid];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = fmaf(a[i + u], wv[u], acc);
+        }
+        for (; i < nw; ++i) acc = fmaf(a[i], W[i * nw + tid], acc);
         y[tid] += acc;
       }
     } else if (tid < m.n_out) {
@@ -139,7 +147,15 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
     const float* W = m.W + (int64_t)l * nw * nw;
     if (tid < nw) {
       float acc = 0.f;
-      for (int j = 0; j < nw; ++j) acc = fmaf(g[j], W[tid * nw + j], acc);
+      int j = 0;
+      for (; j + 16 <= nw; j += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = W[tid * nw + j + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fmaf(g[j + u], wv[u], acc);
+      }
+      for (; j < nw; ++j) acc = fmaf(g[j], W[tid * nw + j], acc);
       gn[tid] = g[tid] + acc * elu_grad_f(tp[l * nw + tid]) * m.scale[l * nw + tid];
     }
     __syncthreads();

@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X dense fp64 matrix peak (vendor; = 256 CU * 4 SIMD * 32 FLOP/clk * 2.4 GHz)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-HMC_EPS = 6.5e-2                   # leapfrog step of the configs[4] rehearsal: acceptance 0.95 at 0.05, 0.65 at 0.07 (tools/hmc_eps_sweep.sh; erratic beyond: leapfrog resonances of the 1597-dimensional Gaussian prior)
+HMC_EPS = 7e-2                   # leapfrog step of the configs[4] rehearsal: acceptance 0.95 at 0.05, 0.65 at 0.07 (tools/hmc_eps_sweep.sh; erratic beyond: leapfrog resonances of the 1597-dimensional Gaussian prior)
 
 
 def parse():
