@@ -103,6 +103,7 @@ SIGNATURES = {
     "finrom_fom_set_band": (C.c_int, [C.c_void_p, C.POINTER(FomBandDesc)]),
     "finrom_fom_set_band_gradient": (C.c_int, [C.c_void_p, C.POINTER(FomBandGradDesc)]),
     "finrom_fom_band_validate": (C.c_int, [C.POINTER(FomBandDesc), C.c_int32, C.c_int32, C.c_int32]),
+    "finrom_fom_solve_rhs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "finrom_fom_last_path": (C.c_int, [C.c_void_p]),
     "finrom_fom_set_small_max": (C.c_int, [C.c_void_p, C.c_int32]),
     "finrom_fom_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 5),

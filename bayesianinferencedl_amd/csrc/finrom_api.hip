@@ -697,6 +697,37 @@ int finrom_fom_set_band_gradient(finrom_fom_t h, const finrom_fom_band_grad_desc
   return 0;
 }
 
+int finrom_fom_solve_rhs(finrom_fom_t h, const double* x, int64_t S, const double* rhs, int32_t nrhs, double* out, int32_t* info,
+                         void* stream) {
+  if (!h || S < 0 || nrhs < 0 || (S > 0 && nrhs > 0 && (!x || !rhs || !out))) { set_error("fom_solve_rhs: bad argument"); return FINROM_ERR_ARG; }
+  if (!h->band.on) { set_error("fom_solve_rhs: needs the band sweep (finrom_fom_set_band)"); return FINROM_ERR_UNSUPPORTED; }
+  if (S == 0 || nrhs == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const FomDev& d = h->d;
+  const BandDev& b = h->band;
+  h->last_path = band_path(b, false);
+  const int64_t dr = (int64_t)nrhs * d.n;
+  const size_t per_sample = ((size_t)b.gsize + d.xdim + 2 * (size_t)dr) * sizeof(double);
+  const int64_t limit = std::max<int64_t>(64, (int64_t)((size_t)48 << 30) / (int64_t)per_sample / 64 * 64);
+  for (int64_t s0 = 0; s0 < S; s0 += limit) {
+    const int64_t Sc = std::min(limit, S - s0), nblk = (Sc + 63) / 64;
+    int rc;
+    if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
+    if ((rc = h->Gw.reserve((size_t)nblk * b.gsize * 64 * sizeof(double)))) return rc;
+    if ((rc = h->gradT.reserve((size_t)nblk * 2 * dr * 64 * sizeof(double)))) return rc;      // rhsT | outT
+    if ((rc = h->qtmp.reserve((size_t)Sc * std::max(d.n_obs, 1) * sizeof(double)))) return rc;
+    double* rhsT = (double*)h->gradT.p;
+    double* outT = rhsT + (size_t)nblk * dr * 64;
+    if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
+    if ((rc = launch_fom_assemble(h->band_asm, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
+    if ((rc = launch_fom_band(b, (double*)h->Gw.p, nblk, Sc, (double*)h->qtmp.p, info ? info + s0 : nullptr, st, false))) return rc;
+    if ((rc = launch_pack(rhs + s0 * dr, Sc, (int)dr, rhsT, st))) return rc;
+    if ((rc = launch_fom_band_resolve(b, (double*)h->Gw.p, nblk, nrhs, rhsT, outT, st))) return rc;
+    if ((rc = launch_unpack(outT, Sc, (int)dr, dr, 0, nullptr, out + s0 * dr, st))) return rc;
+  }
+  return 0;
+}
+
 int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* a) {
   if (!h || !a || a->nops_res < VM_CHUNK || a->nops_res % VM_CHUNK) { set_error("fom_set_gradient: bad argument"); return FINROM_ERR_ARG; }
   FomDev& d = h->d;

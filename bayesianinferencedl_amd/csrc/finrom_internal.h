@@ -173,6 +173,7 @@ struct BandGradDev {              // adjoint gradient on the band layout (finrom
 };
 int launch_fom_band_adjoint(const BandDev& p, const BandGradDev& g, double* Gw, int64_t nblk, int64_t S, const double* qoi,
                             const double* data, int64_t data_stride, double* gradT, double* J, hipStream_t st);
+int launch_fom_band_resolve(const BandDev& p, double* Gw, int64_t nblk, int nrhs, const double* rhsT, double* outT, hipStream_t st);
 constexpr int BAND_LDS_XSIZE = 256;
 bool band_supported(int NSF, int NSP, int NX);
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qoi_only);

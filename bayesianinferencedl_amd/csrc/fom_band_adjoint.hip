@@ -141,6 +141,47 @@ __global__ __launch_bounds__(64) void fom_band_adjoint_kernel(BandDev p, const i
   if (live) Jout[s] = 0.5 * jl;
 }
 
+// ---- general right-hand sides with the stored factor (finrom_fom_solve_rhs: the incremental solves of Fin.hessian_action,
+// fom/forward_solve.py:344-368) -------------------------------------------------------------------------------------------------
+// After the full sweep:  out_k = A^-1 rhs_k  for k < nrhs.  rhsT / outT: sample-blocked [blk][nrhs * n][64] in DOF order (pack_kernel /
+// unpack_w_kernel layouts); the permutation to elimination order happens here (line perm[e] of the block).
+template <int NSF, int NSP, int NXM>
+__global__ __launch_bounds__(64) void fom_band_resolve_kernel(BandDev p, const int* __restrict__ act, const int* __restrict__ lx_ptr,
+                                                              const int* __restrict__ ent_extra, const int* __restrict__ iface_elim,
+                                                              const int* __restrict__ perm, double* __restrict__ Gw, int nrhs,
+                                                              const double* __restrict__ rhsT, double* __restrict__ outT) {
+  extern __shared__ __attribute__((aligned(16))) double alds[];      // [NXM][64] the extras' solution values
+  const int lane = threadIdx.x;
+  const int64_t blk = blockIdx.x;
+  double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;
+  Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000), lane * 8};
+  double* wx = alds + lane;
+  const PostTables T{act, lx_ptr, ent_extra, nullptr, nullptr, nullptr};
+  const int64_t d = (int64_t)nrhs * p.n;
+  for (int k = 0; k < nrhs; ++k) {
+    const double* __restrict__ src = rhsT + (blk * d + (int64_t)k * p.n) * 64 + lane;
+    double* __restrict__ dst = outT + (blk * d + (int64_t)k * p.n) * 64 + lane;
+    for (int e = 0; e < p.n; ++e) io.st(src[(int64_t)perm[e] * 64], p.offV + e);
+    double xy[NXM];
+    static_for<0, NXM>([&](auto i) { xy[decltype(i)::value] = 0.0; });
+    for (int f = 0; f < p.nfins; ++f)
+      band_fsub<NSF, false, NXM, ADJ_RING>(p, io, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF, p.offV, xy);
+    band_fsub<NSP, true, NXM, ADJ_RING>(p, io, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0, p.offV, xy);
+    band_bsweep<NSP, true, NXM, ADJ_RING>(p, io, wx, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0, p.offV);
+    for (int f = 0; f < p.nfins; ++f)
+      band_bsweep<NSF, false, NXM, ADJ_RING>(p, io, wx, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF, p.offV);
+    for (int e = 0; e < p.n; ++e) dst[(int64_t)perm[e] * 64] = io.ld(p.offV + e);
+  }
+}
+
+template <int NSF, int NSP, int NXM>
+int launch_res(const BandDev& p, double* Gw, int64_t nblk, int nrhs, const double* rhsT, double* outT, hipStream_t st) {
+  hipLaunchKernelGGL((fom_band_resolve_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), (size_t)NXM * 64 * sizeof(double), st, p, p.act,
+                     p.lx_ptr, p.ent_extra, p.iface_elim, p.perm, Gw, nrhs, rhsT, outT);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int NSF, int NSP, int NXM>
 int launch_adj(const BandDev& p, const BandGradDev& g, double* Gw, int64_t nblk, int64_t S, const double* qoi, const double* data,
                int64_t data_stride, double* gradT, double* J, hipStream_t st) {
@@ -167,6 +208,16 @@ int launch_fom_band_adjoint(const BandDev& p, const BandGradDev& g, double* Gw, 
   FR_A(3, 6, 4) FR_A(4, 10, 4) FR_A(5, 14, 4) FR_A(6, 18, 8) FR_A(7, 22, 8)
 #undef FR_A
   set_error("fom band adjoint: unsupported window sizes");
+  return FINROM_ERR_UNSUPPORTED;
+}
+
+int launch_fom_band_resolve(const BandDev& p, double* Gw, int64_t nblk, int nrhs, const double* rhsT, double* outT, hipStream_t st) {
+  if (nblk == 0 || nrhs == 0) return 0;
+  ScopedKernelTimer t(p.NSP <= 14 ? K_FOM_PATH_BAND_REG : K_FOM_PATH_BAND_LDSW, st);
+#define FR_R(A, B, X) if (p.NSF == A && p.NSP == B) return launch_res<A, B, X>(p, Gw, nblk, nrhs, rhsT, outT, st);
+  FR_R(3, 6, 4) FR_R(4, 10, 4) FR_R(5, 14, 4) FR_R(6, 18, 8) FR_R(7, 22, 8)
+#undef FR_R
+  set_error("fom band resolve: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }
 

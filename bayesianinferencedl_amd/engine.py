@@ -283,6 +283,20 @@ class FomEngine:
         """Move the batch-size threshold of the small-batch schedule (0: every batch takes the throughput path)."""
         check(lib().finrom_fom_set_small_max(self._h, int(small_max)), "finrom_fom_set_small_max")
 
+    def solve_rhs(self, X, rhs):
+        """X [S, xdim], rhs [S, nrhs, n] (dof order) -> dict(out [S, nrhs, n] = A(x_s)^-1 rhs, info [S]) (finrom_fom_solve_rhs)."""
+        b = _Batch(X, self.xdim)
+        S = b.S
+        rhs = rhs if _is_torch(rhs) else np.ascontiguousarray(rhs, dtype=np.float64)
+        nrhs = int(rhs.shape[-2]) if rhs.ndim == 3 else 1
+        rb = _Batch(rhs, nrhs * self.n)
+        assert rb.S == S, (rb.S, S)
+        out, op = b.new((S, nrhs, self.n), zero=False) if b.torch else b.new((S, nrhs, self.n))
+        info, ip = b.new((S,), "i4")
+        check(lib().finrom_fom_solve_rhs(self._h, b.ptr, S, rb.ptr, nrhs, op, ip, b.stream), "finrom_fom_solve_rhs")
+        _sync_if_mixed(b, rb)
+        return {"out": b.out(out, (S, nrhs, self.n)), "info": b.out(info, (S,), "i4")}
+
     def _enable_gradient(self):
         """One-time tables of the adjoint gradient (finrom_fom_set_gradient)."""
         if self._grad:

@@ -138,22 +138,34 @@ class Fin:
         `forward` / `gradient` (the operator is linear in k; the reference's incremental forms carry exp(k) although its forward
         model does not -- its own TODO, :243-263 -- so its third, exp-only term has no counterpart here):
             A w = F,   A lam = -B^T (B w - d),   A w^ = -A[u] w,   A lam^ = -B^T B w^ - A[u] lam,
-            (H u)_i = lam^^T A_i w + lam^T A_i w^,      A[u] = sum_i u_i A_i.
-        Four sparse solves with one factorisation on the HOST (SciPy SuperLU): an inverse-problem diagnostic outside the hot
-        path (not a row); `GN_hessian_action` and the gradients it is checked against run on the device."""
-        import scipy.sparse.linalg as spl
+            (H u)_i = lam^^T A_i w + lam^T A_i w^,      A[u] = sum_i u_i A_i."""
+        return self.hessian_action_batch(as_nodal(k)[None, :], as_nodal(u_2)[None, :], data)[0]
+
+    def hessian_action_batch(self, K, U, data):
+        """K, U [S, n] -> H(k_s) u_s [S, n].  The four solves per sample run on the device: the forward solve (band sweep), then
+        the adjoint and the incremental state together and the incremental adjoint as general right-hand sides on the stored factor
+        (finrom_fom_solve_rhs; since round 3 -- SciPy SuperLU on the host before).  The right-hand sides in between are two sparse
+        matrix-vector products per sample on the host: an inverse-problem diagnostic, not the hot path (not a row)."""
         ops = self.ops
-        kk, u, d = as_nodal(k), as_nodal(u_2), np.asarray(data, dtype=np.float64)
-        W = ops.W_field
-        lu = spl.splu(ops.csr(ops.robin_vals + W @ kk).tocsc())
-        B = np.asarray(self.B_obs)
-        Au = ops.csr(W @ u)
-        w = lu.solve(np.asarray(ops.F, dtype=np.float64))
-        lam = lu.solve(-(B.T @ (B @ w - d)))
-        w_hat = lu.solve(-(Au @ w))
-        lam_hat = lu.solve(-(B.T @ (B @ w_hat)) - Au @ lam)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(-1, ops.n); U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, ops.n)
+        S = K.shape[0]
+        d = np.broadcast_to(np.asarray(data, dtype=np.float64), (S, self.n_obs))
+        eng = self._engine("field")
+        if eng.band is None:
+            raise NotImplementedError("hessian_action needs the band sweep's stored factor (meshes with a band plan: m <= 20)")
+        Wm, B = ops.W_field, np.asarray(self.B_obs)
+        fwd = eng.solve(K, want_w=True)
+        if np.any(np.asarray(fwd["info"]) != 0):
+            raise np.linalg.LinAlgError("FOM operator not positive definite for this conductivity")
+        w = np.asarray(fwd["w"])
+        Au = [ops.csr(Wm @ U[s]) for s in range(S)]
+        rhs = np.stack([np.stack([-(B.T @ (B @ w[s] - d[s])), -(Au[s] @ w[s])]) for s in range(S)])      # [S, 2, n]
+        r1 = np.asarray(eng.solve_rhs(K, rhs)["out"])
+        lam, w_hat = r1[:, 0], r1[:, 1]
+        rhs2 = np.stack([(-(B.T @ (B @ w_hat[s])) - Au[s] @ lam[s])[None, :] for s in range(S)])          # [S, 1, n]
+        lam_hat = np.asarray(eng.solve_rhs(K, rhs2)["out"])[:, 0]
         rows = np.repeat(np.arange(ops.n), np.diff(ops.indptr)); cols = ops.indices
-        return W.T @ (lam_hat[rows] * w[cols]) + W.T @ (lam[rows] * w_hat[cols])
+        return np.stack([Wm.T @ (lam_hat[s][rows] * w[s][cols]) + Wm.T @ (lam[s][rows] * w_hat[s][cols]) for s in range(S)])
 
     # ---- dense mass and stiffness matrices the reference keeps as attributes (:172-173; not used by the hot loop) ----------
     @property

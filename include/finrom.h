@@ -242,6 +242,14 @@ typedef struct {
 } finrom_fom_band_grad_desc;
 int finrom_fom_set_band_gradient(finrom_fom_t h, const finrom_fom_band_grad_desc* desc);
 
+/* General right-hand sides for the operator of each sample: out[s][k][:] = A(x_s)^-1 rhs[s][k][:], k < nrhs, rhs / out [S x nrhs x n]
+ * row-major in dof order -- the incremental state and incremental adjoint solves of Fin.hessian_action (fom/forward_solve.py:
+ * 344-368: `solve(self._a == rhs)` with a new right-hand side for the same conductivity).  One band sweep factors A(x_s), the
+ * columns then stream back once per right-hand side (forward substitution + backward sweep on the stored factor).  Needs
+ * finrom_fom_set_band (FINROM_ERR_UNSUPPORTED otherwise); info as for finrom_fom_solve. */
+int finrom_fom_solve_rhs(finrom_fom_t h, const double* x, int64_t S, const double* rhs, int32_t nrhs, double* out, int32_t* info,
+                         void* stream);
+
 /* ---- which schedule ran (Fin.forward has ONE solver, fom/forward_solve.py:286; this library has several schedules of the
  * same factorisation, picked by batch size and mesh) ------------------------------------------------------------------- *
  * finrom_fom_last_path: the schedule the most recent finrom_fom_solve / finrom_fom_gradient / finrom_solve_pairs call on

@@ -163,3 +163,38 @@ def test_adjoint_gradient_on_the_band_layout(problems, spaces, m):
     good = np.setdiff1d(np.arange(S), [77])
     ref = fin_i.gradient_batch(X[good], D2[good], params="nine")
     assert _rel(res["grad"][good], ref["grad"]) < 1e-9
+
+
+@pytest.mark.parametrize("m", [12, 20])
+def test_general_right_hand_sides_on_the_stored_factor(spaces, m):
+    """finrom_fom_solve_rhs (the incremental solves of Fin.hessian_action, fom/forward_solve.py:344-368): out = A(x_s)^-1 rhs for
+    three right-hand sides per sample -- dense random ones, so every fin's contribution to the post's right-hand side and every
+    extra's collected right-hand side is exercised -- against SciPy's sparse LU, batch tail included; then the batched Hessian
+    action against central differences of the device gradient."""
+    import scipy.sparse.linalg as spl
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    V = spaces(m)
+    fin = Fin(V)
+    ops = V.operators()
+    eng = fin._engine("field")
+    rng = np.random.default_rng(60 + m)
+    S, nrhs = 70, 3
+    K = np.exp(0.4 * rng.standard_normal((S, ops.n)))
+    R = rng.standard_normal((S, nrhs, ops.n))
+    R[:, 2, :] = 0.0; R[:, 2, rng.integers(0, ops.n, 5)] = 1.0          # a sparse one too
+    res = eng.solve_rhs(K, R)
+    assert eng.last_path() == BAND_PATH[m] and (res["info"] == 0).all()
+    for s in (0, 1, 63, 64, S - 1):
+        lu = spl.splu(ops.csr(ops.robin_vals + ops.W_field @ K[s]).tocsc())
+        for k in range(nrhs):
+            ref = lu.solve(R[s, k])
+            assert np.linalg.norm(res["out"][s, k] - ref) < 1e-10 * np.linalg.norm(ref), (s, k)
+    # Hessian action: symmetric, and the derivative of the device gradient
+    U = rng.standard_normal((4, ops.n)); d = rng.uniform(0.1, 1.0, fin.n_obs)
+    H = fin.hessian_action_batch(K[:4], U, d)
+    eps = 1e-4
+    for s in range(2):
+        fd = (fin.gradient(K[s] + eps * U[s], d) - fin.gradient(K[s] - eps * U[s], d)) / (2 * eps)
+        assert np.linalg.norm(H[s] - fd) < 1e-6 * np.linalg.norm(fd)
+    H01 = fin.hessian_action(K[0], U[1], d)
+    assert abs(U[1] @ H[0] - U[0] @ H01) < 1e-9 * np.linalg.norm(H[0]) * np.linalg.norm(U[1])

@@ -379,9 +379,11 @@ def test_band_value_slots_are_shared_only_when_their_records_are_equal(spaces):
     assert len(bp.compact_slots(*bp.ab_table(ops.robin_vals, Wf))[1]) > 0.9 * 3 * bp.G
 
 
+@pytest.mark.gpu
 def test_hessian_action_is_the_derivative_of_the_gradient(problems, spaces):
-    """`Fin.hessian_action` (reference fom/forward_solve.py:344-368, here consistent with the k-linear forward model): central
-    differences of the ORACLE's adjoint gradient converge to it at second order, and the action is symmetric."""
+    """`Fin.hessian_action` (reference fom/forward_solve.py:344-368, here consistent with the k-linear forward model; its four
+    solves on the device since round 3): central differences of the ORACLE's adjoint gradient converge to it at second order,
+    and the action is symmetric."""
     from oracle import fin_oracle as O
     from bayesianinferencedl_amd.fom.forward_solve import Fin
     m = 4
@@ -395,4 +397,4 @@ def test_hessian_action_is_the_derivative_of_the_gradient(problems, spaces):
         fd = (fo.gradient(k + eps * u, d) - fo.gradient(k - eps * u, d)) / (2 * eps)
         err.append(np.linalg.norm(H - fd) / np.linalg.norm(fd))
     assert err[0] < 1e-5 and err[1] < 1e-7 and err[1] < err[0] / 50          # O(eps^2)
-    assert abs(u2 @ H - u @ fin.hessian_action(k, u2, d)) < 1e-12 * np.linalg.norm(H) * np.linalg.norm(u2)
+    assert abs(u2 @ H - u @ fin.hessian_action(k, u2, d)) < 1e-10 * np.linalg.norm(H) * np.linalg.norm(u2)
