@@ -21,9 +21,11 @@ FWD_CHUNK = int(_os.environ.get("FINROM_FWD_CHUNK", "8"))
 # Parameter vectors of at most FUSED_X_MAX entries (the five / nine fin conductivities) sit in the interpreter's LDS and
 # the op stream assembles A itself (no pre-pass); their slots come out of the row cache so that 7 waves still share a CU.
 FUSED_X_MAX = int(_os.environ.get("FINROM_FUSED_X_MAX", "16"))
-# Batches of at most SMALL_MAX samples (the scalar call surface) use the latency-oriented schedule: one workgroup per
-# sample, 16 lanes per row of L (finrom_fom_set_small).  0 disables it.  Measured cross-over against the interpreter: ~700
-# samples at m = 12 (value vector in LDS, one workgroup per CU), several thousand at m = 20 (value vector in L2).
+# Batches of at most SMALL_MAX samples use the latency-oriented schedule: one workgroup per sample, 16 lanes per row of L
+# (finrom_fom_set_small) -- for GRADIENTS on every mesh, for forward solves only where no band plan is installed (m >= 24):
+# since round 3 the band sweep serves small forward batches too (a lone wave of it: 1.7-2.3 ms at m = 12, 4.2-4.4 ms at m = 20,
+# against 2.7 and 17.9 ms here).  0 disables it.  Measured cross-over against the interpreter: ~700 samples at m = 12 (value
+# vector in LDS, one workgroup per CU), several thousand at m = 20 (value vector in L2).
 SMALL_MAX = int(_os.environ.get("FINROM_SMALL_MAX", "512"))
 SMALL_MAX_GLOBAL = int(_os.environ.get("FINROM_SMALL_MAX_GLOBAL", "4096"))
 # Batches beyond the small-batch schedule use the frontal band sweep (front in registers, csrc/fom_band.hip) when the mesh

@@ -30,8 +30,8 @@ def test_oracle_reproduces_golden(problems):
 def test_gpu_reproduces_golden(spaces, kind, key, schedule, monkeypatch):
     from bayesianinferencedl_amd.pairs import FinPairSolver
     import bayesianinferencedl_amd.engine as E
-    if schedule == "throughput schedule":          # the golden batches are small: also check the band sweep
-        monkeypatch.setattr(E, "SMALL_MAX", 0)
+    if schedule == "small-batch schedule":         # fom_small_kernel: the forward path where no band plan is installed
+        monkeypatch.setattr(E, "USE_BAND", False)
     V = spaces(int(G["m"]))
     res = FinPairSolver(V, G["phi"], params=kind).solve_pairs(G[key], want_w=True, want_w_r=True)
     assert (res["info"] == 0).all()

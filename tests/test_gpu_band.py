@@ -106,21 +106,38 @@ def test_band_sweep_flags_indefinite_samples(spaces, m):
 
 
 @pytest.mark.parametrize("m,small_path,small_max", [(12, "small_lds", 512), (20, "small_global", 4096)])
-def test_dispatch_by_batch_size(spaces, m, small_path, small_max):
-    """finrom_fom_solve's dispatch, asserted: batches up to the handle's threshold take the small-batch schedule (value vector
-    in LDS at m = 12, in the workspace at m = 20), the next size up takes the band sweep; results agree to round-off."""
+def test_dispatch_by_batch_size(spaces, m, small_path, small_max, monkeypatch):
+    """The dispatch, asserted.  FORWARD solves take the band sweep at every batch size once the plan is installed (a lone wave of
+    it beats the level-scheduled small-batch kernel: 1.7 against 2.7 ms at m = 12, 4.2 against 17.9 ms at m = 20); the GRADIENT of
+    a small batch takes the small-batch kernel (value vector in LDS at m = 12, in the workspace at m = 20), of a larger one the
+    band adjoint.  Without a band plan the small-batch kernel is the forward path too.  Results agree to round-off."""
+    import bayesianinferencedl_amd.engine as E
     from bayesianinferencedl_amd.fom.forward_solve import Fin
     fin = Fin(spaces(m))
     eng = fin._engine("nine")
     rng = np.random.default_rng(8)
     X = rng.uniform(0.1, 10.0, (small_max + 1, 9))
-    a = fin.forward_batch(X[:small_max], want_w=False, params="nine")
-    assert eng.last_path() == small_path
+    one = fin.forward_batch(X[:1], want_w=True, params="nine")
+    assert eng.last_path() == BAND_PATH[m]
+    a = fin.forward_batch(X[:64], want_w=False, params="nine")
+    assert eng.last_path() == BAND_PATH[m] + "_qoi"
     b = fin.forward_batch(X, want_w=False, params="nine")
     assert eng.last_path() == BAND_PATH[m] + "_qoi"
+    assert np.array_equal(a["qoi"], b["qoi"][:64]) and _rel(one["qoi"], b["qoi"][:1]) < 1e-11     # same kernel: same numbers
+    data = np.full(9, 0.3)
+    n_small = 40
+    gs = fin.gradient_batch(X[:n_small], data, params="nine")
+    assert eng.last_path() == small_path
+    gl = fin.gradient_batch(X, data, params="nine")
+    assert eng.last_path() == BAND_PATH[m]
+    assert _rel(gs["grad"], gl["grad"][:n_small]) < 1e-9
+    monkeypatch.setattr(E, "USE_BAND", False)
+    fin_nb = Fin(spaces(m))
+    c = fin_nb.forward_batch(X[:64], want_w=False, params="nine")
+    assert fin_nb._engine("nine").last_path() == small_path
     # two schedules of the same factorisation (other elimination order, other summation order): round-off times the operator's
     # condition number (kappa in [0.1, 10]: 2e-12 measured at m = 20), an order below the parity tolerance
-    assert _rel(a["qoi"], b["qoi"][:small_max]) < 1e-11
+    assert _rel(c["qoi"], a["qoi"]) < 1e-11
 
 
 @pytest.mark.parametrize("m", [12, 16, 20])

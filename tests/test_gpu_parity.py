@@ -12,13 +12,17 @@ TOL = 1e-10
 
 @pytest.fixture(autouse=True, params=["small-batch schedule", "throughput schedule"])
 def fom_schedule(request, monkeypatch):
-    """Small batches take the latency-oriented FOM schedule (finrom_fom_set_small); every test here also runs with it
-    not installed, so that the throughput schedule -- the frontal band sweep on every mesh with a band plan (m <= 20), the
-    schedule interpreter otherwise and for the adjoint gradient -- is checked on the same inputs.  (Which kernel ran is
-    asserted where a test is ABOUT a kernel: tests/test_gpu_band.py, test_fwd_chunk_16_..., test_interpreter_forward_path_....)"""
+    """Every test here runs under both families of FOM schedules.  "throughput schedule": the frontal band sweep on every mesh
+    with a band plan (m <= 20; since round 3 it serves small forward batches too), the band adjoint for gradients, no small-batch
+    schedule installed.  "small-batch schedule": no band plan installed, so batches of <= 512 samples take the latency-oriented
+    kernel (fom_small_kernel: the forward path of meshes without window sizes, and every handle's small-batch GRADIENT path) and
+    larger ones the schedule interpreter.  (Which kernel ran is asserted where a test is ABOUT a kernel: tests/test_gpu_band.py,
+    test_fwd_chunk_16_..., test_interpreter_forward_path_....)"""
     import bayesianinferencedl_amd.engine as E
     if request.param == "throughput schedule":
         monkeypatch.setattr(E, "SMALL_MAX", 0)
+    else:
+        monkeypatch.setattr(E, "USE_BAND", False)
     return request.param
 
 
