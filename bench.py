@@ -491,7 +491,8 @@ def run_hmc(args, rank, local_rank, world):
             ach = alg / (ms[dom] * 1e-3) / 1e9
             roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                     "traffic": None, "avg_launch_ms": ms[dom],
-                    "note": "latency-bound workload: one wave per chain walks 2 r pivot steps; lower-bound bytes (factor read twice + vectors)"}
+                    "note": "latency-bound workload: the one-sample solve kernel (one wave per chain factors and substitutes in MFMA form, "
+                            "tiles in LDS) + the gradient contraction; lower-bound bytes of the old packed-factor model, kept as an order of magnitude"}
         cpu = None
         if world == 1 and args.cpu_samples > 0:
             cpu = hmc_cpu_baseline(args, phi, model, solver_r.data, K0, res)
@@ -558,7 +559,7 @@ def roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl)
     rp = (r + 15) // 16 * 16
     per_launch = S * args.steps / max(launches.get(dom, args.steps), 1)          # samples one launch processes
     t = ms[dom] * 1e-3
-    key = f"{args.params}/m{args.m}/r{args.r}/S{S}"
+    key = f"{args.params}/m{args.m}/r{args.r}/S{S}" + ("" if args.projection == "direct" else "/" + args.projection)
 
     def hbm(bytes_per_sample, model):
         alg = per_launch * bytes_per_sample
