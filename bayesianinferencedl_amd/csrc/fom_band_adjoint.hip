@@ -118,20 +118,22 @@ __global__ __launch_bounds__(64) void fom_band_adjoint_kernel(BandDev p, const i
   band_bsweep<NSP, true, NXM, RBP>(p, io, wx, T, nullptr, p.post_e0, p.npost, p.npost, p.post_L0, p.offV);
   for (int f = 0; f < p.nfins; ++f)
     band_bsweep<NSF, false, NXM, RBF>(p, io, wx, T, iface_elim + f * p.nif, f * p.npf, p.npf, p.npf + p.nif, f * p.npf * NSF, p.offV);
-  // grad_j = sum dA_ab/dx_j v_a w_b, loads batched by 4 pairs (a failed factorisation left NaN in w: it propagates)
+  // grad_j = sum dA_ab/dx_j v_a w_b, loads batched by GB pairs (a failed factorisation left NaN in w: it propagates).  16 pairs =
+  // 32 loads in flight: a lone wave (the one-block batches of a scalar caller) is latency-bound on exactly this loop
+  constexpr int GB = 16;
   for (int j = 0; j < p.xdim; ++j) {
     double g0 = 0.0, g1 = 0.0;
     const int t0 = g_ptr[j], t1 = g_ptr[j + 1];
-    for (int t = t0; t < t1; t += 4) {
-      double va[4], wb[4];
+    for (int t = t0; t < t1; t += GB) {
+      double va[GB], wb[GB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < GB; ++u) {
         const int tt = (t + u < t1) ? t + u : t1 - 1;
         va[u] = io.ld(p.offV + g_a[tt]);
         wb[u] = io.ld(p.offY + g_b[tt]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; u += 2) {
+      for (int u = 0; u < GB; u += 2) {
         g0 = fma((t + u < t1) ? g_w[t + u] : 0.0, va[u] * wb[u], g0);
         g1 = fma((t + u + 1 < t1) ? g_w[t + u + 1] : 0.0, va[u + 1] * wb[u + 1], g1);
       }
