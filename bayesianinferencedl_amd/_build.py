@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfinrom_hip.so")
-SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip", "comm.hip"]
+SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_wide.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "finrom_internal.h"), os.path.join(CSRC, "rom_proj_device.h"), os.path.join(CSRC, "fom_band_device.h"), os.path.join(ROOT, "include", "finrom.h")]
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + \
     os.environ.get("FINROM_EXTRA_FLAGS", "").split()      # (A/B builds of tuning constants, e.g. -DADJ_RING=2)
@@ -19,6 +19,7 @@ FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT
 # (chol_tiles + solve_tiles around inline-asm MFMA tuples) from 188 VGPRs to 256 + 388 B of scratch, and the kernel
 # must stay at <= 192 to share SIMDs with the FOM interpreter.  The MFMA main loop is inline asm either way.
 OPT = {"rom_proj_single.hip": "-O2"}
+EXTRA_DEPS = {"fom_band_wide.hip": ["fom_band.hip"]}       # (includes it: same templates, other instantiations)
 
 
 def _hipcc():
@@ -43,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [sp] + HEADERS):
+        if force or _stale(obj, [sp] + HEADERS + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])]):
             jobs.append([hipcc, *FLAGS, OPT.get(src, "-O3"), "-c", sp, "-o", obj])
 
     def run(cmd):

@@ -518,7 +518,7 @@ static int validate_band(const finrom_fom_band_desc* a, int n, int xdim, int n_o
       (d.n_obs > 0 && !a->obs_ptr)) return bad("table pointer (null)");
   for (int e = 0; e < 3 * G; ++e) if (a->abmap[e] < 0 || a->abmap[e] >= a->nAB) return bad("abmap");
   const int64_t nL = (int64_t)a->nfins * a->npf * a->NSF + (int64_t)a->npost * a->NSP;
-  const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n + BAND_LDS_XSIZE + n;      // ... | y -> w | extras (LDS variant) | adjoint
+  const int64_t gsize = (int64_t)a->nAB + nL + a->nLx + n + band_xsize(a->NSP) + n;      // ... | y -> w | extras (LDS variant) | adjoint
   if (gsize * 512 >= (int64_t)1 << 31) { set_error("fom_set_band: workspace too long for 32-bit buffer offsets"); return FINROM_ERR_UNSUPPORTED; }
   if (a->ab_ptr[0] != 0 || a->ab_ptr[a->nAB] != a->nterms) return bad("ab_ptr");
   for (int e = 0; e < a->nAB; ++e) if (a->ab_ptr[e + 1] < a->ab_ptr[e]) return bad("ab_ptr");
@@ -622,7 +622,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   b.NSF = a->NSF; b.NSP = a->NSP; b.NX = a->NX; b.nfins = a->nfins; b.npf = a->npf; b.nif = a->nif; b.npost = a->npost;
   b.post_g0 = a->nfins * (a->npf + a->nif); b.post_e0 = a->nfins * a->npf; b.post_L0 = a->nfins * a->npf * a->NSF;
   b.offL = a->nAB; b.offLx = a->nAB + (int)nL; b.offY = a->nAB + (int)nL + a->nLx; b.offX = b.offY + n;
-  b.offV = b.offX + BAND_LDS_XSIZE;
+  b.offV = b.offX + band_xsize(a->NSP);
   // records of the assembly pre-pass (fom_assemble_kernel): every value slot, so that special slots start at zero
   std::vector<int> reci((size_t)a->nAB * 8, 0);
   std::vector<double> recd((size_t)a->nAB * 5, 0.0);

@@ -155,7 +155,7 @@ int launch_unpack_w(const FomDev& p, const double* Gw, int64_t S, double* w, hip
 struct BandDev {
   int on = 0;
   int n, n_obs, xdim, gsize, nAB, nL, nLx, NSF, NSP, NX, nfins, npf, nif, npost, post_g0, post_e0, post_L0;
-  int offL, offLx, offY, offX;   // offX: the extras' state of the LDS-window variant (BAND_LDS_XSIZE doubles per lane)
+  int offL, offLx, offY, offX;   // offX: the extras' state of the LDS-window variant (band_xsize(NSP) doubles per lane)
   int offV;                      // adjoint right-hand side -> adjoint solution (n doubles; finrom_fom_gradient)
   const int* abmap;          // [3 G] physical value slot of each entry of a segment node
   const double* Fg; const int* act; const int* lx_ptr; const int* ent_extra; const int* ecp_ptr; const int* ecp_slot; const int* ecp_off;
@@ -174,9 +174,12 @@ struct BandGradDev {              // adjoint gradient on the band layout (finrom
 int launch_fom_band_adjoint(const BandDev& p, const BandGradDev& g, double* Gw, int64_t nblk, int64_t S, const double* qoi,
                             const double* data, int64_t data_stride, double* gradT, double* J, hipStream_t st);
 int launch_fom_band_resolve(const BandDev& p, double* Gw, int64_t nblk, int nrhs, const double* rhsT, double* outT, hipStream_t st);
-constexpr int BAND_LDS_XSIZE = 256;
+constexpr int BAND_LDS_XSIZE = 256;                 // doubles per lane of the extras' workspace slice ...
+constexpr int BAND_LDS_XSIZE_WIDE = 384;            // ... and for the windows beyond NSP = 22 (ten extras of 26 slots + their scalars)
+constexpr int band_xsize(int NSP) { return NSP > 22 ? BAND_LDS_XSIZE_WIDE : BAND_LDS_XSIZE; }
 bool band_supported(int NSF, int NSP, int NX);
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qoi_only);
+int launch_fom_band_wide(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qo);   // fom_band_wide.hip
 int band_path(const BandDev& p, bool qoi_only);      // FINROM_FOM_PATH_* of the kernel launch_fom_band picks
 
 // ---- learned error model (mlp_kernels.hip, finrom_mlp_*) ----------------------------------

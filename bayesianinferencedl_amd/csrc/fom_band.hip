@@ -402,6 +402,14 @@ template <int NS, int WV, int WVI> constexpr int dg_off(int d) {
 }
 template <int NS, int WV, int WVI> constexpr int dg_total() { return dg_off<NS, WV, WVI>(NS - 1); }
 
+// LDS of the register variant, doubles per lane: 4 (NS + 1) exchange buffers | the extras' state up to XL::WX | the failure flag.
+// ldsr_xrows: how many of the extras' NXM rows of NS fit into the 160 KB (320 doubles per lane) beside the rest
+template <int NS, int NXM> constexpr int ldsr_xrows() {
+  const int fixed = 4 * (NS + 1) + (XL<NS, NXM>::WX - NXM * NS) + 1, fit = (320 - fixed) / NS;
+  return fit < NXM ? fit : NXM;
+}
+template <int NS, int NXM> constexpr int ldsr_state() { return 4 * (NS + 1) + XL<NS, NXM>::WX - (NXM - ldsr_xrows<NS, NXM>()) * NS; }   // = the flag's index
+
 // ---- the same sweep with the triangle in the owners' REGISTERS ------------------------------------------------------------------
 // The update moves an entry along its diagonal, and a diagonal belongs to one wave: the whole diagonal can live in that wave's
 // registers (in place, ascending: plain register renaming), ~63 doubles per wave at NS = 22.  LDS then only carries what the waves
@@ -417,9 +425,28 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
   constexpr int ST = 0, YU = 1 % WV, E = WV - 1;
   using L = XL<NS, NXM>;
   // the extras' state (wave E only) sits in LDS now that the window has left it: a row update is ~50 LDS operations instead of
-  // a round trip to L2 per extra
-  auto xld = [&](int idx) -> double { return wl[(XOFF + idx) * 64]; };
-  auto xst = [&](double v, int idx) { wl[(XOFF + idx) * 64] = v; };
+  // a round trip to L2 per extra.  Beyond NS = 22 the ten rows no longer fit beside the exchange buffers: the first
+  // ldsr_xrows<NS, NXM>() rows stay in LDS, the others live in the workspace slice p.offX (same index), the scalars behind the
+  // rows move down in LDS by the rows that left
+  constexpr int XR = ldsr_xrows<NS, NXM>(), XSH = (NXM - XR) * NS;
+  auto xld = [&](int idx) -> double { return wl[(XOFF + idx - XSH) * 64]; };                    // the scalars: XD, XY, XX
+  auto xst = [&](double v, int idx) { wl[(XOFF + idx - XSH) * 64] = v; };
+  auto xrld = [&](auto slc, int col) -> double {                                                // row slc (compile-time), slot col
+    constexpr int sl = decltype(slc)::value;
+    if constexpr (sl < XR) return wl[(XOFF + sl * NS + col) * 64]; else return io.ld(p.offX + sl * NS + col);
+  };
+  auto xrst = [&](double v, auto slc, int col) {
+    constexpr int sl = decltype(slc)::value;
+    if constexpr (sl < XR) wl[(XOFF + sl * NS + col) * 64] = v; else io.st(v, p.offX + sl * NS + col);
+  };
+  auto xrld_rt = [&](int sl, int col) -> double {                                               // (row known at run time only)
+    if constexpr (XR == NXM) return wl[(XOFF + sl * NS + col) * 64];
+    else return sl < XR ? wl[(XOFF + sl * NS + col) * 64] : io.ld(p.offX + sl * NS + col);
+  };
+  auto xrst_rt = [&](double v, int sl, int col) {
+    if constexpr (XR == NXM) wl[(XOFF + sl * NS + col) * 64] = v;
+    else { if (sl < XR) wl[(XOFF + sl * NS + col) * 64] = v; else io.st(v, p.offX + sl * NS + col); }
+  };
   // LDS-only barrier: nothing a wave stores to the workspace inside this sweep is read by another wave before the sweep ends
   // (the caller's __syncthreads()), and __syncthreads() here would make every pivot wait for the column stores' acknowledgements
   auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -432,13 +459,13 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
     double row[P + 1];
     static_for<0, P>([&](auto kc) { row[decltype(kc)::value] = 0.0; });
     double diag = 0.0, yv = 0.0;
-    static_for<0, NXM>([&](auto sc) { xst(0.0, L::X + decltype(sc)::value * NS + u); });
+    static_for<0, NXM>([&](auto sc) { xrst(0.0, sc, u); });
     if (ex != 0) {
       const int sl = ex - 1;
       static_for<0, P>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         int sk = u - P + k; sk += sk < 0 ? NS : 0;
-        row[k] = xld(L::X + sl * NS + sk);
+        row[k] = xrld_rt(sl, sk);
       });
       diag = xld(L::XD + sl); yv = xld(L::XY + sl);
       double xo[NXM];
@@ -451,11 +478,11 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
         constexpr int o = decltype(oc)::value;
         if (o != sl) {
           const int a = o > sl ? o : sl, b = o > sl ? sl : o;
-          xst(xo[o], L::X + o * NS + u);
+          xrst(xo[o], oc, u);
           xst(0.0, L::XX + a * (a - 1) / 2 + b);
         }
       });
-      for (int v = 0; v < NS; ++v) xst(0.0, L::X + sl * NS + v);
+      for (int v = 0; v < NS; ++v) xrst_rt(0.0, sl, v);
       xst(0.0, L::XD + sl); xst(0.0, L::XY + sl);
     }
     if constexpr (P >= 1) row[P - 1] += ab1;
@@ -466,8 +493,8 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
     if constexpr (!PRO) wl[(COL + par * RS + B) * 64] = row[0];      // its coupling to the next pivot: the last entry of that pivot's column
     if constexpr (PRO && P == B) corner = row[0];
     for (int c = c0; c < c1; ++c) {
-      const int idx = L::X + T.ecp_slot[c] * NS + u;
-      xst(xld(idx) + io.ld(T.ecp_off[c]), idx);
+      const int sl = T.ecp_slot[c];
+      xrst_rt(xrld_rt(sl, u) + io.ld(T.ecp_off[c]), sl, u);
     }
   };
 
@@ -498,7 +525,8 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
   static_for<0, NS>([&](auto sc) { yv[decltype(sc)::value] = 0.0; });
   if constexpr (WVI == E) {
     static_for<0, 4 * RS>([&](auto i) { wl[decltype(i)::value * 64] = 0.0; });
-    for (int i = 0; i < L::WX; ++i) xst(0.0, i);
+    for (int i = L::XD; i < L::WX; ++i) xst(0.0, i);
+    for (int sl = 0; sl < NXM; ++sl) for (int v = 0; v < NS; ++v) xrst_rt(0.0, sl, v);
   }
   barrier();
   static_for<0, NS>([&](auto pc) {
@@ -589,7 +617,7 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
             static_for<0, NS>([&](auto tc) {
               constexpr int t = decltype(tc)::value;
               int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
-              xv[t] = xld(L::X + sl * NS + st_);
+              xv[t] = xrld(sc, st_);
             });
             const double xy = xld(L::XY + sl), xd = xld(L::XD + sl);
             const double v = xv[0] * inv;
@@ -600,7 +628,7 @@ __device__ __forceinline__ void band_sweep_ldsr(const BandDev& p, const Io& io, 
             static_for<1, NS>([&](auto tc) {
               constexpr int t = decltype(tc)::value;
               int st_ = u + t; st_ -= st_ >= NS ? NS : 0;
-              xst(fma(-v, l[t], xv[t]), L::X + sl * NS + st_);
+              xrst(fma(-v, l[t], xv[t]), sc, st_);
             });
           }
         });
@@ -835,10 +863,12 @@ __global__ __launch_bounds__(64) void fom_band_lds_kernel(BandDev p, const int* 
 // What is left is mostly those scalar loads: they share lgkmcnt with the LDS reads, so every wait for an LDS value also waits
 // for them; shipping them through LDS as well (complete pivot records built by the loaders) made the LOADERS wait for them
 // instead (2.8 ms).
+// (columns per chunk: six while two buffers of them fit; four at NS = 26, where the loaders' register sets shrink with it)
+constexpr int bsweep_cb(int NS) { return NS > 22 ? 4 : 6; }
 template <int NS, int NXM, int WV, int WVI>
 __device__ __forceinline__ void band_bsweep_ldsw(const BandDev& p, const Io& io, double* __restrict__ xs, const PostTables& T, int e0,
                                                  int npiv, int L0) {
-  constexpr int CB = 6, COLS = NS + 1, BUF = CB * COLS, WXO = 2 * BUF;       // LDS (doubles per lane): 2 x CB x (NS + 1) | WX[NXM]
+  constexpr int CB = bsweep_cb(NS), COLS = NS + 1, BUF = CB * COLS, WXO = 2 * BUF;       // LDS (doubles per lane): 2 x CB x (NS + 1) | WX[NXM]
   constexpr int U = NS / gcd_c(NS, CB) * CB;                                   // unroll: window slots and chunk positions compile-time
   constexpr int NP = WV - 1;                                                   // loader waves
   static_assert(WV >= 2 && (2 * BUF + NXM) * 512 <= 160 * 1024, "ring fits LDS (launch_ldsw sizes the allocation)");
@@ -866,7 +896,7 @@ __device__ __forceinline__ void band_bsweep_ldsw(const BandDev& p, const Io& io,
   };
   if constexpr (WVI == 0) static_for<0, NXM>([&](auto sc) { xs[(WXO + decltype(sc)::value) * 64] = 0.0; });
   if constexpr (WVI > 0) {
-    constexpr int DL = 4;
+    constexpr int DL = NS > 22 ? 3 : 4;
     double cs[DL][MA][COLS];
     static_for<0, DL>([&](auto dc) { constexpr int d = decltype(dc)::value; fetch(kmax - d, cs[d]); });
     deposit(kmax, 0, cs[0]);
@@ -889,7 +919,7 @@ __device__ __forceinline__ void band_bsweep_ldsw(const BandDev& p, const Io& io,
     double ww[NS];
     static_for<0, NS>([&](auto i) { ww[decltype(i)::value] = 0.0; });
     // (a pivot takes ~0.6 us here: the couplings are requested RT = 6 pivots ahead, the scalars they depend on three more)
-    constexpr int RT = 6;
+    constexpr int RT = NS > 22 ? 4 : 6;                 // (a divisor of the unroll U where that keeps the code size down)
     double lxv[RT][NXM];
     int am_r[RT], ex_r[RT];
     struct Q { int am, k, ex; };
@@ -959,7 +989,7 @@ __device__ __forceinline__ void fom_band_ldsw_body(const BandDev& p, const int* 
   Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, p.gsize * 512, 0x00020000), lane * 8};
   double* xs = xlds + lane;
   const PostTables T{act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off};
-  constexpr int FLAG = 4 * (NSP + 1) + XL<NSP, NXM>::WX;               // behind the forward sweep's buffers
+  constexpr int FLAG = ldsr_state<NSP, NXM>();                         // behind the forward sweep's buffers
   int bad = 0;
   constexpr int NIFT = (NSF - 1) * NSF / 2;
   long long tk[6];
@@ -1048,9 +1078,9 @@ __global__ __launch_bounds__(64 * WV) void fom_band_ldsw_kernel(FR_BAND_ARGS) { 
 template <int NSF, int NSP, bool QO, int NXM = 8>
 int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int WV = 4;
-  static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
-  constexpr size_t lds_w = (size_t)(4 * (NSP + 1) + XL<NSP, NXM>::WX + 1) * 64 * sizeof(double);      // forward: column / row buffers | extras' state | flag
-  constexpr size_t lds_b = (size_t)(2 * 6 * (NSP + 1) + NXM) * 64 * sizeof(double);      // backward: two buffers of six columns + WX
+  static_assert(XL<NSP, NXM>::SIZE <= band_xsize(NSP), "workspace slice of the extras");
+  constexpr size_t lds_w = (size_t)(ldsr_state<NSP, NXM>() + 1) * 64 * sizeof(double);      // forward: column / row buffers | extras' state | flag
+  constexpr size_t lds_b = (size_t)(2 * bsweep_cb(NSP) * (NSP + 1) + NXM) * 64 * sizeof(double);      // backward: two buffers of CB columns + WX
   constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
   static_assert(lds <= 160 * 1024, "LDS window");
   static PerDeviceOnce once;
@@ -1065,7 +1095,7 @@ int launch_ldsw(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* q
 template <int NSF, int NSP>
 int launch_lds(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st) {
   constexpr int NXM = 8;
-  static_assert(XL<NSP, NXM>::SIZE <= BAND_LDS_XSIZE, "workspace slice of the extras");
+  static_assert(XL<NSP, NXM>::SIZE <= band_xsize(NSP), "workspace slice of the extras");
   constexpr size_t lds_w = (size_t)(NSP * (NSP + 1) / 2 + NSP) * 64 * sizeof(double);            // forward: window + y
   constexpr size_t lds_b = (size_t)(XL<NSP, NXM>::WX + NXM) * 64 * sizeof(double);               // backward: XL::WX at its usual index
   constexpr size_t lds = lds_w > lds_b ? lds_w : lds_b;
@@ -1090,9 +1120,20 @@ int launch_t(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi,
 
 }  // namespace
 
+#define FR_W4(A, B, X) if (p.NSF == A && p.NSP == B) return qo ? launch_ldsw<A, B, true, X>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<A, B, false, X>(p, Gw, nblk, S, qoi, info, st);
+#ifdef FINROM_BAND_TU_WIDE
+// second translation unit (fom_band_wide.hip includes this file with FINROM_BAND_TU_WIDE defined): the NSP = 26 kernels alone take
+// as long to compile as everything else in here
+int launch_fom_band_wide(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qo) {
+  FR_W4(8, 26, 10)
+  set_error("fom band sweep: unsupported window sizes");
+  return FINROM_ERR_UNSUPPORTED;
+}
+#else
 bool band_supported(int NSF, int NSP, int NX) {
   if (NX <= 4 && ((NSF == 3 && NSP == 6) || (NSF == 4 && NSP == 10) || (NSF == 5 && NSP == 14))) return true;      // window in registers
-  return NX <= 8 && ((NSF == 6 && NSP == 18) || (NSF == 7 && NSP == 22));                                           // window in LDS
+  if (NX <= 8 && ((NSF == 6 && NSP == 18) || (NSF == 7 && NSP == 22))) return true;                                 // window over four waves
+  return NX <= 10 && NSF == 8 && NSP == 26;                                                                         // (some of the extras' rows in the workspace)
 }
 
 static bool band_one_wave_lds() {
@@ -1124,11 +1165,13 @@ int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, doubl
   if (one_wave && p.NSF == 6 && p.NSP == 18) return launch_lds<6, 18>(p, Gw, nblk, S, qoi, info, st);
   if (one_wave && p.NSF == 7 && p.NSP == 22) return launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st);
 #endif
-#define FR_W4(A, B) if (p.NSF == A && p.NSP == B) return qo ? launch_ldsw<A, B, true>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<A, B, false>(p, Gw, nblk, S, qoi, info, st);
-  FR_W4(6, 18) FR_W4(7, 22)
-#undef FR_W4
+  FR_W4(6, 18, 8) FR_W4(7, 22, 8)
+  if (p.NSP == 26) return launch_fom_band_wide(p, Gw, nblk, S, qoi, info, st, qo);
   set_error("fom band sweep: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }
+
+#endif
+#undef FR_W4
 
 }  // namespace finrom
