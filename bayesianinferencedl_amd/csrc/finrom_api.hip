@@ -334,7 +334,7 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
   // Small batches: where the mesh has a band plan the band sweep serves them too -- ONE wave walking its 1597 pivots takes 1.7 ms
   // (QoI only) / 2.3 ms (with w) at m = 12 and 4.2 / 4.4 ms at m = 20, the level-scheduled small-batch kernel 2.7 and 17.9 ms
   // (tools/fom_small_vs_band.py) -- so the latency-oriented schedule (one workgroup per sample) is the forward path only of
-  // meshes without window sizes (m >= 28); finrom_fom_gradient keeps it for small batches (its adjoint stage beats a lone wave
+  // meshes without window sizes (m >= 32); finrom_fom_gradient keeps it for small batches (its adjoint stage beats a lone wave
   // of the band adjoint kernel: 3.1 against 10 ms).
   if (h->small.small_max > 0 && S <= h->small.small_max && !(h->band.on && !env_no_band)) {
     if (!(stages & 2)) return 0;

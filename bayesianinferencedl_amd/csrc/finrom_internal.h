@@ -176,7 +176,7 @@ int launch_fom_band_adjoint(const BandDev& p, const BandGradDev& g, double* Gw, 
 int launch_fom_band_resolve(const BandDev& p, double* Gw, int64_t nblk, int nrhs, const double* rhsT, double* outT, hipStream_t st);
 constexpr int BAND_LDS_XSIZE = 256;                 // doubles per lane of the extras' workspace slice ...
 constexpr int BAND_LDS_XSIZE_WIDE = 384;            // ... and for the windows beyond NSP = 22 (ten extras of 26 slots + their scalars)
-constexpr int band_xsize(int NSP) { return NSP > 22 ? BAND_LDS_XSIZE_WIDE : BAND_LDS_XSIZE; }
+constexpr int band_xsize(int NSP) { return NSP > 26 ? 512 : NSP > 22 ? BAND_LDS_XSIZE_WIDE : BAND_LDS_XSIZE; }   // (NSP = 30, twelve extras: 462)
 bool band_supported(int NSF, int NSP, int NX);
 int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qoi_only);
 int launch_fom_band_wide(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qo);   // fom_band_wide.hip

@@ -1122,10 +1122,10 @@ int launch_t(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi,
 
 #define FR_W4(A, B, X) if (p.NSF == A && p.NSP == B) return qo ? launch_ldsw<A, B, true, X>(p, Gw, nblk, S, qoi, info, st) : launch_ldsw<A, B, false, X>(p, Gw, nblk, S, qoi, info, st);
 #ifdef FINROM_BAND_TU_WIDE
-// second translation unit (fom_band_wide.hip includes this file with FINROM_BAND_TU_WIDE defined): the NSP = 26 kernels alone take
+// second translation unit (fom_band_wide.hip includes this file with FINROM_BAND_TU_WIDE defined): the NSP = 26, 30 kernels alone take
 // as long to compile as everything else in here
 int launch_fom_band_wide(const BandDev& p, double* Gw, int64_t nblk, int64_t S, double* qoi, int* info, hipStream_t st, bool qo) {
-  FR_W4(8, 26, 10)
+  FR_W4(8, 26, 10) FR_W4(9, 30, 12)
   set_error("fom band sweep: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }
@@ -1133,7 +1133,7 @@ int launch_fom_band_wide(const BandDev& p, double* Gw, int64_t nblk, int64_t S, 
 bool band_supported(int NSF, int NSP, int NX) {
   if (NX <= 4 && ((NSF == 3 && NSP == 6) || (NSF == 4 && NSP == 10) || (NSF == 5 && NSP == 14))) return true;      // window in registers
   if (NX <= 8 && ((NSF == 6 && NSP == 18) || (NSF == 7 && NSP == 22))) return true;                                 // window over four waves
-  return NX <= 10 && NSF == 8 && NSP == 26;                                                                         // (some of the extras' rows in the workspace)
+  return (NX <= 10 && NSF == 8 && NSP == 26) || (NX <= 12 && NSF == 9 && NSP == 30);                               // (some of the extras' rows in the workspace)
 }
 
 static bool band_one_wave_lds() {
@@ -1166,7 +1166,7 @@ int launch_fom_band(const BandDev& p, double* Gw, int64_t nblk, int64_t S, doubl
   if (one_wave && p.NSF == 7 && p.NSP == 22) return launch_lds<7, 22>(p, Gw, nblk, S, qoi, info, st);
 #endif
   FR_W4(6, 18, 8) FR_W4(7, 22, 8)
-  if (p.NSP == 26) return launch_fom_band_wide(p, Gw, nblk, S, qoi, info, st, qo);
+  if (p.NSP >= 26) return launch_fom_band_wide(p, Gw, nblk, S, qoi, info, st, qo);
   set_error("fom band sweep: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
 }

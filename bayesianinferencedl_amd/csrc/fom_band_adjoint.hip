@@ -205,9 +205,9 @@ int launch_fom_band_adjoint(const BandDev& p, const BandGradDev& g, double* Gw, 
                             const double* data, int64_t data_stride, double* gradT, double* J, hipStream_t st) {
   if (nblk == 0) return 0;
   ScopedKernelTimer t(p.NSP <= 14 ? K_FOM_PATH_BAND_REG : K_FOM_PATH_BAND_LDSW, st);
-  if ((size_t)(p.n_obs + 10) * 64 * sizeof(double) > 160 * 1024) { set_error("fom band adjoint: too many observations for LDS"); return FINROM_ERR_UNSUPPORTED; }
+  if ((size_t)(p.n_obs + 12) * 64 * sizeof(double) > 160 * 1024) { set_error("fom band adjoint: too many observations for LDS"); return FINROM_ERR_UNSUPPORTED; }
 #define FR_A(A, B, X) if (p.NSF == A && p.NSP == B) return launch_adj<A, B, X>(p, g, Gw, nblk, S, qoi, data, data_stride, gradT, J, st);
-  FR_A(3, 6, 4) FR_A(4, 10, 4) FR_A(5, 14, 4) FR_A(6, 18, 8) FR_A(7, 22, 8) FR_A(8, 26, 10)
+  FR_A(3, 6, 4) FR_A(4, 10, 4) FR_A(5, 14, 4) FR_A(6, 18, 8) FR_A(7, 22, 8) FR_A(8, 26, 10) FR_A(9, 30, 12)
 #undef FR_A
   set_error("fom band adjoint: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;
@@ -217,7 +217,7 @@ int launch_fom_band_resolve(const BandDev& p, double* Gw, int64_t nblk, int nrhs
   if (nblk == 0 || nrhs == 0) return 0;
   ScopedKernelTimer t(p.NSP <= 14 ? K_FOM_PATH_BAND_REG : K_FOM_PATH_BAND_LDSW, st);
 #define FR_R(A, B, X) if (p.NSF == A && p.NSP == B) return launch_res<A, B, X>(p, Gw, nblk, nrhs, rhsT, outT, st);
-  FR_R(3, 6, 4) FR_R(4, 10, 4) FR_R(5, 14, 4) FR_R(6, 18, 8) FR_R(7, 22, 8) FR_R(8, 26, 10)
+  FR_R(3, 6, 4) FR_R(4, 10, 4) FR_R(5, 14, 4) FR_R(6, 18, 8) FR_R(7, 22, 8) FR_R(8, 26, 10) FR_R(9, 30, 12)
 #undef FR_R
   set_error("fom band resolve: unsupported window sizes");
   return FINROM_ERR_UNSUPPORTED;

@@ -22,7 +22,7 @@ FWD_CHUNK = int(_os.environ.get("FINROM_FWD_CHUNK", "8"))
 # the op stream assembles A itself (no pre-pass); their slots come out of the row cache so that 7 waves still share a CU.
 FUSED_X_MAX = int(_os.environ.get("FINROM_FUSED_X_MAX", "16"))
 # Batches of at most SMALL_MAX samples use the latency-oriented schedule: one workgroup per sample, 16 lanes per row of L
-# (finrom_fom_set_small) -- for GRADIENTS on every mesh, for forward solves only where no band plan is installed (m >= 28):
+# (finrom_fom_set_small) -- for GRADIENTS on every mesh, for forward solves only where no band plan is installed (m >= 32):
 # since round 3 the band sweep serves small forward batches too (a lone wave of it: 1.7-2.3 ms at m = 12, 4.2-4.4 ms at m = 20,
 # against 2.7 and 17.9 ms here).  0 disables it.  Measured cross-over against the interpreter: ~700 samples at m = 12 (value
 # vector in LDS, one workgroup per CU), several thousand at m = 20 (value vector in L2).

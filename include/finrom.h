@@ -194,7 +194,7 @@ int finrom_fom_set_small(finrom_fom_t h, const finrom_fom_small_desc* desc);
  * updates (their L values are stored at lx_ptr[p]..), ent_extra[p] = slot + 1 if node p was an extra before it entered the
  * window, (ecp_slot, ecp_off) in [ecp_ptr[p], ecp_ptr[p+1]) = couplings AB[off] of node p to extras, set when p enters.
  * Supported windows: (NSF, NSP) = (3, 6), (4, 10), (5, 14) (m = 4, 8, 12; window in registers), NX <= 4, and (6, 18), (7, 22)
- * (m = 16, 20; the post's window over four waves), NX <= 8, and (8, 26) (m = 24, same kernel), NX <= 10; otherwise FINROM_ERR_UNSUPPORTED and the handle keeps using the
+ * (m = 16, 20; the post's window over four waves), NX <= 8, and (8, 26), NX <= 10, (9, 30), NX <= 12 (m = 24, 28; same kernel); otherwise FINROM_ERR_UNSUPPORTED and the handle keeps using the
  * interpreter -- as it does when the load Fg is not zero on the fins' own nodes (the sweep does not carry a fin's load to its
  * interface).  finrom_fom_gradient uses the band layout once finrom_fom_set_band_gradient has installed its tables. */
 typedef struct {
@@ -262,7 +262,7 @@ int finrom_fom_solve_rhs(finrom_fom_t h, const double* x, int64_t S, const doubl
 #define FINROM_FOM_PATH_SMALL_GLOBAL 2     /* fom_small_kernel<false>: value vector in the workspace */
 #define FINROM_FOM_PATH_INTERPRETER 3      /* fom_vm_kernel + fom_bwd_kernel (schedule interpreter) */
 #define FINROM_FOM_PATH_BAND_REGISTERS 4   /* fom_band_kernel: frontal band sweep, front in registers (m <= 12) */
-#define FINROM_FOM_PATH_BAND_LDS_4WAVE 5   /* fom_band_ldsw_kernel: post's window over four waves + LDS exchange (m = 16, 20, 24) */
+#define FINROM_FOM_PATH_BAND_LDS_4WAVE 5   /* fom_band_ldsw_kernel: post's window over four waves + LDS exchange (m = 16 ... 28) */
 #define FINROM_FOM_PATH_BAND_LDS_1WAVE 6   /* fom_band_lds_kernel: one-wave LDS window (A/B builds only) */
 #define FINROM_FOM_PATH_BAND_REGISTERS_QOI 7   /* fom_band_kernel, QoI-only form: fins ride as functionals, no w */
 #define FINROM_FOM_PATH_BAND_LDS_4WAVE_QOI 8   /* fom_band_ldsw_kernel, QoI-only form */

@@ -1,7 +1,7 @@
 """The frontal band sweep (csrc/fom_band.hip) against the oracle and against the schedule interpreter it replaces on the
 throughput path: w and QoI <= 1e-10 relative for nodal fields and for five / nine fin conductivities, on every mesh the library
 has window sizes for -- the front in registers (m = 4, 8, 12: fom_band_kernel) and the post's window over four waves with LDS as
-the exchange (m = 16, 20, 24: fom_band_ldsw_kernel; at m = 24 half of the extras' rows live in the workspace), each in its full form (w wanted) and in its QoI-only form -- failure flags for
+the exchange (m = 16, 20, 24, 28: fom_band_ldsw_kernel; from m = 24 on some of the extras' rows live in the workspace), each in its full form (w wanted) and in its QoI-only form -- failure flags for
 indefinite operators, batch tails.
 
 Every case ASSERTS WHICH KERNEL RAN (finrom_fom_last_path): the small-batch schedule takes batches of <= 512 samples (<= 4096
@@ -16,7 +16,7 @@ from oracle import fin_oracle as O
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
 BAND_PATH = {4: "band_registers", 8: "band_registers", 12: "band_registers", 16: "band_lds_4wave", 20: "band_lds_4wave",
-             24: "band_lds_4wave"}
+             24: "band_lds_4wave", 28: "band_lds_4wave"}
 
 
 def _rel(a, b):
@@ -45,7 +45,7 @@ def _throughput_engines(V, kinds=("field", "nine", "five")):
     return fin, fin_i
 
 
-@pytest.mark.parametrize("m", [4, 8, 12, 16, 20, 24])
+@pytest.mark.parametrize("m", [4, 8, 12, 16, 20, 24, 28])
 def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
     prob, V = problems(m), spaces(m)
     fo = O.FinOracle(prob)
@@ -80,7 +80,7 @@ def test_band_sweep_matches_oracle_and_interpreter(problems, spaces, m):
             assert np.linalg.norm(res_q["qoi"][s] - q) < TOL * np.linalg.norm(q), (params, s, "qoi-only")
 
 
-@pytest.mark.parametrize("m", [12, 16, 20, 24])
+@pytest.mark.parametrize("m", [12, 16, 20, 24, 28])
 def test_band_sweep_flags_indefinite_samples(spaces, m):
     """A negative conductivity in every fin (the failure is seen by a FIN's sweep -- in the four-wave kernel by whichever wave
     swept that fin) and one in the centre post only (seen by the post's sweep): both samples are flagged and NaN, nobody else
@@ -141,7 +141,7 @@ def test_dispatch_by_batch_size(spaces, m, small_path, small_max, monkeypatch):
     assert _rel(c["qoi"], a["qoi"]) < 1e-11
 
 
-@pytest.mark.parametrize("m", [12, 16, 20, 24])
+@pytest.mark.parametrize("m", [12, 16, 20, 24, 28])
 def test_adjoint_gradient_on_the_band_layout(problems, spaces, m):
     """finrom_fom_gradient for batches beyond the small-batch schedule (Fin.gradient, fom/forward_solve.py:293-322): the full
     band sweep leaves the factor and w in the workspace, fom_band_adjoint_kernel solves the adjoint with the stored columns

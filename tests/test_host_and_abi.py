@@ -256,7 +256,7 @@ def test_fused_assembly_stream_replays_to_the_same_solution(spaces, params):
     assert np.linalg.norm(w - ref) < 1e-12 * np.linalg.norm(ref)
 
 
-@pytest.mark.parametrize("m", [4, 8, 12, 20, 24])      # 20: the plan of the four-wave variant (8 extras); 24: ten extras
+@pytest.mark.parametrize("m", [4, 8, 12, 20, 24, 28])      # 20: the plan of the four-wave variant (8 extras); 24: ten extras; 28: twelve
 def test_band_plan_replay_solves_the_fom(spaces, m):
     """bandplan.py: fin-by-fin, then up the post -- the tables of the frontal band sweep (windows of NS slots renamed
     cyclically, fin Schur complements added to the post's entries, long-range couplings carried as extras) replayed in NumPy
@@ -264,7 +264,7 @@ def test_band_plan_replay_solves_the_fom(spaces, m):
     import scipy.sparse as sp
     ops = spaces(m).operators()
     bp = ops.band_plan()
-    assert bp is not None and (bp.NSF, bp.NSP) == (m // 4 + 2, m + 2) and bp.NX <= (4 if m <= 12 else 8 if m <= 20 else 10)
+    assert bp is not None and (bp.NSF, bp.NSP) == (m // 4 + 2, m + 2) and bp.NX <= (4 if m <= 12 else 8 if m <= 20 else 10 if m <= 24 else 12)
     assert sorted(bp.perm.tolist()) == list(range(ops.n))
     assert bp.lx_ptr[-1] == bp.nLx and bp.nLx == sum(bin(int(a)).count("1") for a in bp.act)
     rng = np.random.default_rng(m)
