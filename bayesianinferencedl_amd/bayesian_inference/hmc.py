@@ -95,13 +95,20 @@ def romml_value_and_grad(solver_r):
 
 
 def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, sigma=0.05, tau=0.5, mean=None, record=None,
-                      keep_trace=False, graph=True, data=None):
-    """`run_chains` with the chains' state RESIDENT ON THE DEVICE (torch tensors on the current CUDA device): positions, momenta and
-    potential gradients never visit the host inside a trajectory.  One leapfrog step = a few elementwise kernels around ONE
-    library call (finrom_romml_grad on the tensors in place); with graph=True that step is captured once in a HIP graph
-    (torch.cuda.CUDAGraph: the library launches on torch's capture stream) and replayed, so a step costs the host one graph
-    launch.  The host sees two scalars per chain and proposal (the Hamiltonians, for the Metropolis test with the same NumPy
-    streams as run_chains) -- one synchronisation per proposal instead of three copies and one per evaluation.
+                      keep_trace=False, graph=True, data=None, block=32):
+    """`run_chains` with the chains RESIDENT ON THE DEVICE (torch tensors on the current CUDA device): positions, momenta,
+    potentials, the Metropolis test and the accept counters never visit the host.  A whole PROPOSAL -- momentum in, n_leapfrog
+    steps of (a few elementwise kernels around ONE library call, finrom_romml_grad on the tensors in place), Hamiltonians,
+    accept / reject, state update -- is captured once in a HIP graph (torch.cuda.CUDAGraph: the library launches on torch's capture
+    stream) and replayed: one graph launch per proposal, no synchronisation until the chain ends.  The random numbers are the
+    host chain's: every chain's NumPy generator is drawn in the same order (n normals for the momentum, then one uniform), `block`
+    proposals ahead -- the draws do not depend on the state -- while the device works on the previous block, and uploaded
+    block by block; the graph picks its proposal's slice by a device-side counter.  (First version: one graph per leapfrog step
+    and one synchronisation per proposal; the ~25 small launches and two copies around each trajectory were a quarter of
+    the time, tools/graph_call_cost.py.)
+
+    Proposals that contain an evaluation index listed in `record` run the same operations in stream order, step by step, so that
+    the evaluation's input, loss and gradient can be copied out.  graph=False: everything in stream order.
 
     Same chains as run_chains(romml_value_and_grad(solver_r), ...) up to the rounding of the elementwise updates.
     Returns HmcResult(K [C, n] (NumPy), accept, proposals, n_evals, recorded, trace, graph: whether a graph was replayed)."""
@@ -115,7 +122,17 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
     rngs = [np.random.default_rng(s) for s in seeds]
     assert len(rngs) == C
     c_lik, c_pri = 1.0 / sigma ** 2, 1.0 / tau ** 2
+    n_prop = max(0, (n_evals - 1) // n_leapfrog)
+    B = max(1, min(block, n_prop))
+    # static tensors (the graph's operands): state K, U, dU | work Kq, Pq, D, dUq | inputs P_dev, lu_dev | counters
     Kq, Pq, D, dUq = (torch.empty_like(K) for _ in range(4))
+    U, dU = torch.zeros(C, **f64), torch.zeros_like(K)
+    P_dev, lu_dev = torch.zeros(B, C, n, **f64), torch.zeros(B, C, **f64)
+    P0, lu = torch.zeros(1, C, n, **f64), torch.zeros(1, C, **f64)
+    jt = torch.zeros(1, dtype=torch.int64, device=dev)                # proposal inside the uploaded block
+    pt = torch.zeros(1, dtype=torch.int64, device=dev)                # proposal of the chain (trace row)
+    acc = torch.zeros(C, dtype=torch.int64, device=dev)
+    trace = torch.zeros(n_prop + 1, C, n, **f64) if keep_trace else None
     out = {}
 
     def evaluate():
@@ -132,8 +149,8 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
         Pq.add_(dUq, alpha=-eps)                                   # two half steps; the ends of a trajectory correct by +- eps/2
 
     def potential_now():
-        U = out["loss"] * c_lik + 0.5 * c_pri * (D * D).sum(1)
-        return torch.where(out["info"].ne(0) | ~torch.isfinite(U), torch.full_like(U, float("inf")), U)
+        Uv = out["loss"] * c_lik + 0.5 * c_pri * (D * D).sum(1)
+        return torch.where(out["info"].ne(0) | ~torch.isfinite(Uv), torch.full_like(Uv, float("inf")), Uv)
 
     recorded, evals = [], 0
 
@@ -143,58 +160,75 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
             recorded.append((evals, Kq.cpu().numpy().copy(), out["loss"].cpu().numpy().copy(), out["grad"].cpu().numpy().copy()))
         evals += 1
 
-    Kq.copy_(K); Pq.zero_()
-    evaluate()                                                      # evaluation 0: the starting point (also warms the library up)
-    note()
-    U = potential_now()
-    if not bool(torch.isfinite(U).all()):
-        raise ValueError("HMC start point has an indefinite reduced operator")
-    dU = dUq.clone()
-    g = None
-    if graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                           # warm-up on a side stream, as torch's graph recipe asks
-                Kq_save, Pq_save, d_save = Kq.clone(), Pq.clone(), dUq.clone()
-                for _ in range(2):
-                    step()
-                Kq.copy_(Kq_save); Pq.copy_(Pq_save); dUq.copy_(d_save)
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step()
-            Kq.copy_(Kq_save); Pq.copy_(Pq_save); dUq.copy_(d_save)      # (the capture does not run the step; restore anyway)
-        except Exception as exc:                                    # no graph support for this sequence: plain stream order
-            import warnings
-            warnings.warn(f"hmc: HIP graph capture failed ({exc!r}); the leapfrog steps are launched one by one")
-            g = None
-    trace = [K.cpu().numpy().copy()] if keep_trace else None
-    accept = np.zeros(C, np.int64)
-    proposals = 0
-    P_host = np.empty((C, n))
-    while evals + n_leapfrog <= n_evals:
-        for c_, r in enumerate(rngs):
-            P_host[c_] = r.standard_normal(n)
-        P0 = torch.as_tensor(P_host, **f64)
-        H0 = U + 0.5 * (P0 * P0).sum(1)
+    def proposal(hook=None):
+        """One proposal on the static tensors: momentum and log u of slice jt, trajectory, Metropolis test, state update."""
+        torch.index_select(P_dev, 0, jt, out=P0)
+        torch.index_select(lu_dev, 0, jt, out=lu)
+        H0 = U + 0.5 * (P0[0] * P0[0]).sum(1)
         Kq.copy_(K); dUq.copy_(dU)
-        torch.add(P0, dUq, alpha=-0.5 * eps, out=Pq)                # first half step
-        for _ in range(n_leapfrog):
-            g.replay() if g is not None else step()
-            note()
+        torch.add(P0[0], dUq, alpha=-0.5 * eps, out=Pq)             # first half step
+        for _ in range(n_leapfrog):                                 # each step's input depends on the previous gradient
+            step()
+            if hook is not None:
+                hook()
         Pq.add_(dUq, alpha=0.5 * eps)                               # the last update was a whole step: back to a half
         Uq = potential_now()
         H1 = Uq + 0.5 * (Pq * Pq).sum(1)
-        h = torch.stack([H0, H1]).cpu().numpy()                     # the proposal's one synchronisation
-        u = np.array([r.uniform() for r in rngs])
-        with np.errstate(over="ignore", invalid="ignore"):
-            ok = np.isfinite(h[1]) & (np.log(u) < h[0] - h[1])
-        ok_t = torch.as_tensor(ok, device=dev)
-        K = torch.where(ok_t[:, None], Kq, K); U = torch.where(ok_t, Uq, U); dU = torch.where(ok_t[:, None], dUq, dU)
-        accept += ok
-        proposals += 1
-        if keep_trace:
-            trace.append(K.cpu().numpy().copy())
-    return HmcResult(K=K.cpu().numpy(), accept=accept, proposals=proposals, n_evals=evals, recorded=recorded,
-                     trace=np.stack(trace) if keep_trace else None, graph=g is not None)
+        ok = torch.isfinite(H1) & (lu[0] < H0 - H1)                 # (inf - inf = nan compares false, as on the host)
+        K.copy_(torch.where(ok[:, None], Kq, K)); U.copy_(torch.where(ok, Uq, U)); dU.copy_(torch.where(ok[:, None], dUq, dU))
+        acc.add_(ok)
+        jt.add_(1); pt.add_(1)
+        if trace is not None:
+            trace.index_copy_(0, pt, K[None])
+
+    Kq.copy_(K); Pq.zero_()
+    evaluate()                                                      # evaluation 0: the starting point (also warms the library up)
+    note()
+    U.copy_(potential_now())
+    if not bool(torch.isfinite(U).all()):
+        raise ValueError("HMC start point has an indefinite reduced operator")
+    dU.copy_(dUq)
+    if trace is not None:
+        trace[0].copy_(K)
+    g = None
+    if graph and n_prop > 0:
+        try:
+            state = [t.clone() for t in (K, U, dU, acc, jt, pt)]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                           # warm-up on a side stream, as torch's graph recipe asks
+                proposal()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                proposal()
+            for t, t0 in zip((K, U, dU, acc, jt, pt), state):       # (the warm-up moved the state; the capture does not run)
+                t.copy_(t0)
+        except Exception as exc:                                    # no graph support for this sequence: plain stream order
+            import warnings
+            warnings.warn(f"hmc: HIP graph capture failed ({exc!r}); the proposals are launched kernel by kernel")
+            g = None
+            for t, t0 in zip((K, U, dU, acc, jt, pt), state):
+                t.copy_(t0)
+    done = 0
+    while done < n_prop:
+        nb = min(B, n_prop - done)
+        P_host, lu_host = np.zeros((B, C, n)), np.zeros((B, C))
+        for j in range(nb):                                         # the host chain's draws, in its order (overlaps the device's
+            for c_, r in enumerate(rngs):                           #  work on the previous block: nothing here waits for it)
+                P_host[j, c_] = r.standard_normal(n)
+            with np.errstate(divide="ignore"):
+                lu_host[j] = np.log(np.array([r.uniform() for r in rngs]))
+        P_dev.copy_(torch.from_numpy(P_host)); lu_dev.copy_(torch.from_numpy(lu_host))
+        jt.zero_()
+        for j in range(nb):
+            first = 1 + (done + j) * n_leapfrog                     # evaluation indices of this proposal: first .. first + L - 1
+            if record is not None and any(first <= e < first + n_leapfrog for e in record):
+                assert evals == first
+                proposal(hook=note)
+            else:
+                g.replay() if g is not None else proposal()
+                evals += n_leapfrog
+        done += nb
+    return HmcResult(K=K.cpu().numpy(), accept=acc.cpu().numpy(), proposals=n_prop, n_evals=evals, recorded=recorded,
+                     trace=trace.cpu().numpy() if trace is not None else None, graph=g is not None)

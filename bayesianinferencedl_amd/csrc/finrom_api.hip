@@ -99,8 +99,19 @@ struct finrom_rom_s {
   int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
   RomGramDev gram;                     // offline/online form (finrom_rom_set_gram); gram.h is filled at create
   int projection = FINROM_PROJECTION_DIRECT;
-  hipStream_t side = nullptr;          // library-owned stream for the ROM half of finrom_solve_pairs
+  hipStream_t side = nullptr;          // library-owned stream for the ROM half of finrom_solve_pairs / the error model of finrom_romml_grad
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int ensure_side() {
+    if (side) return 0;
+    int lo = 0, hi = 0;
+    FR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // numerically lower = higher priority
+    FR_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
+    FR_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    FR_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    return 0;
+  }
+  // finrom_romml_grad -> finrom_rom_grad (one-sample form only): leave the gradient's partial sums to the consumer; where they are
+  bool defer_gsum = false; const double* last_gpart = nullptr;
 };
 struct finrom_sampler_s { double* U = nullptr; int n = 0; Scratch xi; };
 struct finrom_mlp_s { MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp; };
@@ -1248,6 +1259,8 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
         FR_HIP(hipMemset(h->grad_ticket.p, 0, ROM_SPLITK_MAX_S * sizeof(int)));
       }
       ga.vw = (double*)h->vw.p; ga.gpart = (double*)((char*)h->vw.p + vw_bytes); ga.ticket = (int*)h->grad_ticket.p;
+      ga.defer_sum = h->defer_gsum && s0 == 0 && Sc == S;
+      h->last_gpart = ga.defer_sum ? ga.gpart : nullptr;
       if ((rc = launch_rom_onesample(d, theta + s0 * d.P, Sc, (double*)h->part.p, 1, ga, w_r ? w_r + s0 * d.r : nullptr, q,
                                      info ? info + s0 : nullptr, st))) return rc;
       if ((rc = launch_rom_grad_contract_small(d, Sc, ga, st))) return rc;
@@ -1322,14 +1335,8 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   if (fom->d.n_obs != rom->d.n_obs) { set_error("solve_pairs: FOM and ROM observation operators differ in size"); return FINROM_ERR_ARG; }
   if (S == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (!rom->side) {
-    int lo = 0, hi = 0;
-    FR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // numerically lower = higher priority
-    FR_HIP(hipStreamCreateWithPriority(&rom->side, hipStreamNonBlocking, hi));
-    FR_HIP(hipEventCreateWithFlags(&rom->ev_fork, hipEventDisableTiming));
-    FR_HIP(hipEventCreateWithFlags(&rom->ev_join, hipEventDisableTiming));
-  }
   int rc;
+  if ((rc = rom->ensure_side())) return rc;
   if (!theta) {
     if ((rc = rom->theta.reserve((size_t)S * rom->d.P * sizeof(double)))) return rc;
     theta = (double*)rom->theta.p;
@@ -1478,15 +1485,27 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
   if (!e_nn) { if ((rc = mlp->etmp.reserve((size_t)S * no * sizeof(double)))) return rc; e_nn = (double*)mlp->etmp.p; }
   const int64_t stride = data_per_sample ? no : 0;
   // (the sub-fin averages theta = S k are formed inside the network's forward kernel: it reads k anyway)
+  // One-sample form (the ROM's contraction + solve kernels, S <= 64): the gradient contraction leaves its partial sums to the
+  // error model's backward kernel instead of fencing and drawing tickets for a last workgroup (-7 us per call).
+  // (Tried and removed: under stream capture, the error model's forward kernel on a side stream beside the ROM's contraction
+  // kernel -- the solve kernel is the first to need its output.  One fork / join inside a replayed graph cost ~240 us per call
+  // on this runtime: 113 -> 355 us, tools/graph_call_cost.py.)
+  const bool one = rom->projection == FINROM_PROJECTION_DIRECT && rom_onesample_applies(rom->d, S) && getenv("FINROM_OLD_SUBST") == nullptr &&
+                   rom->g_npairs > 0;
   if (P <= 16) {
     if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st, Sop, P, (double*)mlp->theta.p))) return rc;
   } else {
     if ((rc = launch_subfin_avg(Sop, P, m.n_in, k, S, (double*)mlp->theta.p, st))) return rc;
     if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st))) return rc;
   }
-  if ((rc = finrom_rom_grad(rom, (const double*)mlp->theta.p, (const double*)mlp->shift.p, 1, S, loss, (double*)mlp->gth.p, nullptr,
-                            qoi_r, info, st))) return rc;
-  return launch_mlp_backward(m, S, (const float*)mlp->tape.p, data, stride, qoi_r, e_nn, (const double*)mlp->gth.p, Sop, P, grad, st);
+  rom->defer_gsum = one; rom->last_gpart = nullptr;
+  rc = finrom_rom_grad(rom, (const double*)mlp->theta.p, (const double*)mlp->shift.p, 1, S, loss, (double*)mlp->gth.p, nullptr,
+                       qoi_r, info, st);
+  const double* gparts = rom->last_gpart;
+  rom->defer_gsum = false; rom->last_gpart = nullptr;
+  if (rc) return rc;
+  return launch_mlp_backward(m, S, (const float*)mlp->tape.p, data, stride, qoi_r, e_nn, (const double*)mlp->gth.p, Sop, P, grad, st,
+                             gparts, gparts ? ROM_GRAD_SMALL_NG : 0);
 }
 
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {

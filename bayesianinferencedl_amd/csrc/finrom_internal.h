@@ -193,8 +193,10 @@ struct MlpDev {
 int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double* data, int64_t data_stride, float* tape,
                        double* e_out, double* data_shift, hipStream_t st, const double* Sop = nullptr, int P = 0,
                        double* theta_out = nullptr);
+// (g_parts, n_parts: instead of g_theta, its n_parts partial sums [S x n_parts x 32] as rom_grad_contract_small_kernel leaves them)
 int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
-                        const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st);
+                        const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st,
+                        const double* g_parts = nullptr, int n_parts = 0);
 
 // ---- ROM ------------------------------------------------------------------------------
 constexpr int ROM_MAX_PHASES = 8;
@@ -235,6 +237,7 @@ struct RomGradArgs {                      // adjoint-gradient stage of rom_solve
   double* J = nullptr; double* g = nullptr;                 // [S], [S x P]
   int npairs = 0; const int* pair_p = nullptr; const int* pair_i = nullptr; const double* Gt = nullptr;
   double* gpart = nullptr; int* ticket = nullptr;   // small batches (rom_grad_contract_small_kernel): [S x NG x 32] partial sums, [S] arrival counters (zero between calls)
+  int defer_sum = 0;        // (small batches) leave the NG partial sums in gpart: the consumer adds them (mlp_backward_kernel in finrom_romml_grad)
   double* vw = nullptr;     // scratch [S x 2 rp]: when set, the substitution kernel leaves v_r and w_r there and the
                             // contraction g_i = sum_p theta_p v_r^T G_pi w_r runs in rom_grad_contract_kernel (fp64 MFMA, 16 samples per wave)
 };

@@ -20,6 +20,8 @@ constexpr int MLP_PARTS = 16;        // threads per hidden unit in the first lay
                                      // 1597 x 50 dependent-load multiply-adds per sample and the call is latency-bound -- 100 rows
                                      // per thread, 32 loads in flight, instead of 400 rows with 4 parts: 28 -> ~10 us)
 constexpr int MLP_THREADS = 64 * MLP_PARTS;
+constexpr int MLP_SPLIT = 8;         // workgroups per sample in the backward kernel's one-sample form ...
+constexpr int MLP_SPLIT_MAX_S = 64;  // ... which serves calls of up to this many samples
 
 // e_out[s][o] (double) = network output; data_shift[s][o] = data[o] - e_out (what the ROM adjoint is run against)
 // (Sop, P, theta_out: when given, the sub-fin averages theta = S k of the same field (fom/forward_solve.py:466-480) are formed here
@@ -32,33 +34,39 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, cons
   extern __shared__ float xs[];                        // [n_in] input, then scratch
   __shared__ float part[MLP_PARTS][MLP_MAX_W];
   __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
-  __shared__ double tred[MLP_PARTS][16];
+  __shared__ double tred[MLP_PARTS];
   const int64_t s = blockIdx.x;
   const int tid = threadIdx.x, nw = m.n_w;
-  double th[16];
+  for (int i = tid; i < m.n_in; i += MLP_THREADS) xs[i] = (float)k[s * m.n_in + i];
+  if (theta_out != nullptr) {
+    // theta_p = sum_i Sop[p][i] k[i] in fp64: row p belongs to the waves p WPR .. p WPR + WPR - 1 (WPR = 16 / P: three waves per row
+    // for five averages), a wave's slice dealt over its lanes in coalesced passes of 64, 13 passes requested at a time; ONE
+    // value per wave to reduce across lanes.  (The first version had every thread carry all 16 partial sums through the input
+    // loop and every wave reduce all of them: 16 x 6 shuffles of doubles per wave, 11.8 of the kernel's 25 us; now 4.6.)
+    const int wave = tid >> 6, lane = tid & 63, WPR = MLP_PARTS / P, p = wave / WPR, part_ = wave - p * WPR;
+    double v = 0.0;
+    if (p < P) {
+      const int i0 = (int)((int64_t)m.n_in * part_ / WPR), i1 = (int)((int64_t)m.n_in * (part_ + 1) / WPR);
+      const double* __restrict__ srow = Sop + (int64_t)p * m.n_in;
+      const double* __restrict__ krow = k + s * m.n_in;
+      double v2 = 0.0;
+      for (int i = i0 + lane; i < i1; i += 64 * 13) {
+        double sv[13], kv[13];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) th[p] = 0.0;
-  for (int i = tid; i < m.n_in; i += MLP_THREADS) {
-    const double kv = k[s * m.n_in + i];
-    xs[i] = (float)kv;
-    if (theta_out != nullptr) {
+        for (int u = 0; u < 13; ++u) { const int ii = i + 64 * u; const bool ok = ii < i1; sv[u] = ok ? srow[ii] : 0.0; kv[u] = ok ? krow[ii] : 0.0; }
 #pragma unroll
-      for (int p = 0; p < 16; ++p) if (p < P) th[p] = fma(Sop[(int64_t)p * m.n_in + i], kv, th[p]);
-    }
-  }
-  if (theta_out != nullptr) {                          // wave reduction, then the four waves in order
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      double v = th[p];
+        for (int u = 0; u < 13; ++u) { if (u & 1) v2 = fma(sv[u], kv[u], v2); else v = fma(sv[u], kv[u], v); }
+      }
+      v += v2;
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if ((tid & 63) == 0) tred[tid >> 6][p] = v;
     }
+    if (lane == 0) tred[wave] = v;
   }
   __syncthreads();
-  if (theta_out != nullptr && tid < P) {               // the waves' partial sums in a fixed order
+  if (theta_out != nullptr && tid < P) {               // the row's waves in a fixed order
+    const int WPR = MLP_PARTS / P;
     double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < MLP_PARTS; ++w) t += tred[w][tid];
+    for (int wv = 0; wv < WPR; ++wv) t += tred[tid * WPR + wv];
     theta_out[s * P + tid] = t;
   }
   {                                                   // y0 = W0^T x + b0: unit j = tid % 64, part p = tid / 64 of the rows
@@ -120,11 +128,16 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, cons
 
 // grad[s][i] = sum_p g_theta[s][p] Sop[p][i]  -  sum_j g0[j] W0[i][j],  g0 = d(1/2 |r|^2)/d(y0) with upstream r = data - (qoi_r + e)
 // loss[s] = 1/2 |r|^2 is recomputed here from the same residual (the ROM kernel's J is that of the shifted data: the same number)
+// (NP > 1, calls of up to MLP_SPLIT_MAX_S samples: every one of a sample's NP workgroups walks back through the head and the hidden
+// layers -- the same few microseconds, side by side -- and then takes n_in / NP rows of the first layer's transpose: 320 KB of
+// weights that otherwise pass through ONE CU's L1)
+template <int NP>
 __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int64_t S, const float* __restrict__ tape,
                                                            const double* __restrict__ data, int64_t data_stride,
                                                            const double* __restrict__ qoi_r, const double* __restrict__ e_nn,
                                                            const double* __restrict__ g_theta, const double* __restrict__ Sop,
-                                                           int P, double* __restrict__ grad) {
+                                                           int P, double* __restrict__ grad, const double* __restrict__ g_parts,
+                                                           int n_parts) {
   __shared__ float g[MLP_MAX_W], gn[MLP_MAX_W], up[MLP_MAX_W];
   __shared__ double gth[32];
   const int64_t s = blockIdx.x;
@@ -134,7 +147,13 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
     const double r = data[(data_stride ? s * data_stride : 0) + tid] - (qoi_r[s * m.n_out + tid] + e_nn[s * m.n_out + tid]);
     up[tid] = (float)r;                                // dLoss/d(output) handed to vjp is +r; the minus sign comes at the end
   }
-  if (tid < P) gth[tid] = g_theta != nullptr ? g_theta[s * P + tid] : 0.0;
+  if (tid < P) {
+    double t = 0.0;
+    if (g_parts != nullptr) {                          // the contraction's partial sums, in its own fixed order
+      for (int w = 0; w < n_parts; ++w) t += g_parts[(s * n_parts + w) * 32 + tid];
+    } else if (g_theta != nullptr) t = g_theta[s * P + tid];
+    gth[tid] = t;
+  }
   __syncthreads();
   if (tid < nw) {                                      // through the head: no skip connection
     float acc = 0.f;
@@ -162,7 +181,9 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
     if (tid < nw) g[tid] = gn[tid];
     __syncthreads();
   }
-  for (int i = tid; i < m.n_in; i += MLP_THREADS) {
+  const int wg = NP > 1 ? (int)blockIdx.y : 0;
+  const int r0 = (int)((int64_t)m.n_in * wg / NP), r1 = (int)((int64_t)m.n_in * (wg + 1) / NP);
+  for (int i = r0 + tid; i < r1; i += MLP_THREADS) {
     float acc = 0.f;
     {
       const float* __restrict__ wrow = m.W0 + (int64_t)i * nw;
@@ -196,11 +217,16 @@ int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double
 }
 
 int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
-                        const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st) {
+                        const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st,
+                        const double* g_parts, int n_parts) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_MISC, st);
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3((unsigned)S), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride, qoi_r, e_nn, g_theta,
-                     Sop, P, grad);
+  if (S <= MLP_SPLIT_MAX_S)
+    hipLaunchKernelGGL(mlp_backward_kernel<MLP_SPLIT>, dim3((unsigned)S, MLP_SPLIT), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride,
+                       qoi_r, e_nn, g_theta, Sop, P, grad, g_parts, n_parts);
+  else
+    hipLaunchKernelGGL(mlp_backward_kernel<1>, dim3((unsigned)S), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride, qoi_r, e_nn,
+                       g_theta, Sop, P, grad, g_parts, n_parts);
   FR_HIP(hipGetLastError());
   return 0;
 }

@@ -806,6 +806,7 @@ __global__ __launch_bounds__(256) void rom_grad_contract_small_kernel(RomDev p, 
     __syncthreads();
   }
   if (tid < 32) ga.gpart[(s * NG + grp) * 32 + tid] = gacc[tid];
+  if (ga.defer_sum) return;                              // the next kernel in the stream adds the NG partial sums (no fence, no ticket)
   __threadfence();
   __syncthreads();
   __shared__ int last_s;

@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--chains", type=int, default=4, help="hmc: number of independent chains (sharded over the GPUs)")
     ap.add_argument("--hmc-mode", default="device", choices=["device", "host"],
                     help="hmc: 'device' keeps positions / momenta / gradients in HBM across a trajectory and replays one captured "
-                         "HIP graph per leapfrog step (hmc.run_chains_device); 'host' is round 2's NumPy recursion around one library "
+                         "HIP graph per proposal (hmc.run_chains_device); 'host' is round 2's NumPy recursion around one library "
                          "call per evaluation (three copies and a synchronisation each)")
     ap.add_argument("--hmc-eps", type=float, default=None, help="hmc: leapfrog step size (default: tuned for 60-90 %% acceptance)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],

@@ -62,10 +62,11 @@ def test_hmc_chains_value_and_gradient_match_the_oracle(setup, projection):
 
 @pytest.mark.parametrize("graph", [True, False])
 def test_device_resident_chains_walk_the_host_chains_path(setup, graph):
-    """hmc.run_chains_device -- positions, momenta and gradients stay on the device, one captured HIP graph per leapfrog step
-    (graph=True) or the same launches in stream order -- must walk the path of the host recursion with the same seeds
-    (the elementwise updates round differently: 1e-9), accept the same proposals, and its recorded evaluations must match
-    the oracle like the host chain's do.  eps large enough that proposals ARE rejected (a chain that accepts everything does
+    """hmc.run_chains_device -- positions, momenta, gradients, the Metropolis test and the accept counters stay on the device, one
+    captured HIP graph per PROPOSAL (graph=True) or the same launches in stream order -- must walk the path of the host recursion
+    with the same seeds (the elementwise updates round differently: 1e-9), accept the same proposals, and its recorded
+    evaluations must match the oracle like the host chain's do.  The proposals that hold a recorded evaluation (3 of 12) run step
+    by step, the others through the graph.  eps large enough that proposals ARE rejected (a chain that accepts everything does
     not exercise the accept / reject bookkeeping)."""
     from bayesianinferencedl_amd.bayesian_inference import hmc
     from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
@@ -88,6 +89,29 @@ def test_device_resident_chains_walk_the_host_chains_path(setup, graph):
         assert np.linalg.norm(grad - gradh) <= 1e-6 * np.linalg.norm(gradh), ev
         go, lo = O.grad_romml_oracle(ro, model, K[2])
         assert abs(loss[2] - lo) <= 2e-5 * abs(lo) and np.linalg.norm(grad[2] - go) <= 1e-5 * np.linalg.norm(go), ev
+
+
+@pytest.mark.parametrize("graph,block", [(True, 32), (True, 5), (False, 7)])
+def test_device_chains_without_host_round_trips_reproduce_the_host_chains(setup, graph, block):
+    """Nothing recorded: every proposal is one graph replay (or the same kernels in stream order) and the host sees the chain
+    only at its end.  Random numbers drawn `block` proposals ahead and uploaded block by block (block = 5: blocks of 5, 5, 4;
+    the device-side slice counter restarts per block): same accepted proposals, same end points, same per-proposal trace as the
+    host recursion."""
+    from bayesianinferencedl_amd.bayesian_inference import hmc
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    V, phi, model, data, ro = setup
+    rom = AffineROMFin(V, model, phi); rom.set_data(data)
+    chains = [0, 1, 2, 3]
+    K0 = np.stack([np.exp(0.1 * np.random.default_rng(6 + c).standard_normal(V.dim())) for c in chains])
+    kw = dict(seeds=[100 + c for c in chains], eps=3e-2, n_leapfrog=10, keep_trace=True)
+    host = hmc.run_chains(hmc.romml_value_and_grad(rom), K0, 141, **kw)
+    dev = hmc.run_chains_device(rom, K0, 141, graph=graph, block=block, **kw)
+    assert dev.graph == graph and dev.n_evals == host.n_evals == 141 and dev.proposals == host.proposals == 14
+    assert 0 < host.accept.sum() < 4 * 14, host.accept
+    assert np.array_equal(dev.accept, host.accept)
+    assert dev.trace.shape == host.trace.shape == (15, 4, V.dim())
+    assert np.max(np.abs(dev.trace - host.trace)) <= 1e-9 * np.max(np.abs(host.trace))
+    assert np.linalg.norm(dev.K - host.K) <= 1e-9 * np.linalg.norm(host.K)
 
 
 def test_bench_hmc_mode_contract():
