@@ -91,14 +91,44 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
   const int64_t s = blockIdx.x;
   const int q = lane >> 4, c = lane & 15;
   // the NC partial triangles, added in a fixed order: tile t by wave t % 4
+#ifdef FINROM_SOLVE_CLOCKS
+  long long ck[8]; ck[0] = wall_clock64(); ck[6] = 0;
+#endif
   const double* __restrict__ src = part + (s * NC * (int64_t)NT) * 256;
-  for (int t = wave; t < NT; t += 4) {
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int j = 0; j < NC; ++j)
+  // (a wave's tiles three at a time, eight partials of each requested together: the sums are a few trips to L2, and one tile per
+  // trip -- the first version -- made this phase 12 of the kernel's 50 us)
+  {
+    constexpr int TB = 3, JB = 8;
+    for (int t0 = wave; t0 < NT; t0 += 4 * TB) {
+      double a[TB][4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) a[g] += src[(j * NT + t) * 256 + g * 64 + lane];
+      for (int u = 0; u < TB; ++u)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) tl[t * 256 + g * 64 + lane] = a[g];
+        for (int g = 0; g < 4; ++g) a[u][g] = 0.0;
+      for (int j0 = 0; j0 < NC; j0 += JB) {
+        double v[TB][JB][4];
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+          for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int t = t0 + 4 * u, j = j0 + jj;
+              v[u][jj][g] = (t < NT && j < NC) ? src[(j * NT + t) * 256 + g * 64 + lane] : 0.0;
+            }
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+          for (int jj = 0; jj < JB; ++jj)                // (partials in index order: the same sums as one at a time)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a[u][g] += v[u][jj][g];
+      }
+#pragma unroll
+      for (int u = 0; u < TB; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (t0 + 4 * u < NT) tl[(t0 + 4 * u) * 256 + g * 64 + lane] = a[u][g];
+    }
   }
   if (wave == 0) {
     if (lane == 0) { th[0] = 1.0; th[p.P + 1] = 0.0; }
@@ -106,6 +136,9 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
   }
   __syncthreads();
   if (wave > 0) return;
+#ifdef FINROM_SOLVE_CLOCKS
+  ck[1] = wall_clock64();
+#endif
 
   // B_r = psi^T F (rom :297): F is non-zero on the root nodes only; their rows of psi are rebuilt here
   {
@@ -136,6 +169,9 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
     }
   }
   __builtin_amdgcn_wave_barrier();
+#ifdef FINROM_SOLVE_CLOCKS
+  ck[2] = wall_clock64();
+#endif
 
   auto tile_at = [&](int ti, int tj) -> double* { return tl + (ti * NB - (ti * (ti - 1)) / 2 + (tj - ti)) * 256; };
   const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.obs_phi), 0, p.n_obs * p.r * 8, 0x00020000);
@@ -167,28 +203,47 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
     for (int g = 0; g < 4; ++g)
       if (q + 4 * g == c && 16 * kb + c >= p.r) T[0][g] = 1.0;
     // left-looking: minus what the block rows above contribute (their U tiles in LDS, natural layout = the operand layouts)
-    sfor<0, kb>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      const double* ujk = tile_at(j, kb);
+    // (every operand of the block row is requested from LDS before the first MFMA: left to the compiler, most MFMAs waited for
+    // their own ds_read)
+    if constexpr (kb > 0) {
+      double ua[kb][4], ub[kb][NB - kb][4];
+      sfor<0, kb>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const double* ujk = tile_at(j, kb);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const double ua = -ujk[nat + 64 * g];           // A operand of k-step g: U(j, kb)[k = q + 4 g][i = c]
+        for (int g = 0; g < 4; ++g) ua[j][g] = -ujk[nat + 64 * g];      // A operand of k-step g: U(j, kb)[k = q + 4 g][i = c]
         sfor<kb, NB>([&](auto tc) {
           constexpr int tj = decltype(tc)::value;
-          T[tj - kb] = mma(ua, tile_at(j, tj)[nat + 64 * g], T[tj - kb]);
+          const double* ujt = tile_at(j, tj);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) ub[j][tj - kb][g] = ujt[nat + 64 * g];
         });
-        e = mma(ua, z[j][g], e);
-      }
-    });
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      sfor<0, kb>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          sfor<kb, NB>([&](auto tc) {
+            constexpr int tj = decltype(tc)::value;
+            T[tj - kb] = mma(ua[j][g], ub[j][tj - kb][g], T[tj - kb]);
+          });
+          e = mma(ua[j][g], z[j][g], e);
+        }
+      });
+    }
     // (a) the diagonal tile: 16 elimination steps on [T_kk | I]; M^T is carried (column operations), which is M as an A operand
     double Am[4];
+#ifdef FINROM_SOLVE_CLOCKS
+    const long long cd0 = wall_clock64();
+#endif
     {
       v4d& D = T[0];
 #pragma unroll
       for (int g = 0; g < 4; ++g) Am[g] = (q + 4 * g == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int gs = 0; gs < 4; ++gs)
-#pragma unroll 1
+#pragma unroll
         for (int qs = 0; qs < 4; ++qs) {
           const int st = 4 * gs + qs;
           const double piv = read_lane_f64(D[gs], qs * 16 + st);
@@ -213,6 +268,9 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
           }
         }
     }
+#ifdef FINROM_SOLVE_CLOCKS
+    ck[6] += wall_clock64() - cd0;
+#endif
     // M_kb, natural layout, for the backward sweep: Am[g] at lane (q, c) is M[c][q + 4 g]
 #pragma unroll
     for (int g = 0; g < 4; ++g) mbuf[kb * 256 + trn + 4 * g] = Am[g];
@@ -234,6 +292,9 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
     }
     __builtin_amdgcn_wave_barrier();
   });
+#ifdef FINROM_SOLVE_CLOCKS
+  ck[3] = wall_clock64();
+#endif
   // ---- middle ----------------------------------------------------------------------------------------------------------------
   double part_q = 0.0;
   sfor<0, NB>([&](auto kc) {
@@ -264,6 +325,9 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
       }
     });
   }
+#ifdef FINROM_SOLVE_CLOCKS
+  ck[4] = wall_clock64();
+#endif
   // ---- backward: X_kb = M_kb^T (R_kb - sum_{j > kb} U(kb, j) X_j); X overwrites Z block by block ----------------------------------
   sfor<0, NB>([&](auto kc) {
     constexpr int kb = NB - 1 - decltype(kc)::value;
@@ -279,6 +343,10 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
     for (int g = 0; g < 4; ++g) n = mma(mbuf[kb * 256 + nat + 64 * g], rr[g], n);   // A operand of M^T R: M[k = q + 4 g][i = c]
     z[kb] = n;
   });
+#ifdef FINROM_SOLVE_CLOCKS
+  ck[5] = wall_clock64();
+  if (lane == 0 && qoi_r != nullptr) { for (int i = 0; i < 5; ++i) qoi_r[s * p.n_obs + i] = (double)(ck[i + 1] - ck[i]); qoi_r[s * p.n_obs + 5] = (double)ck[6]; }
+#endif
   const int R = p.rp;
   if (c <= 1) {                                         // column 0 of X is w_r, column 1 v_r
     double* dst = grad ? ga.vw + s * (int64_t)(2 * R) + (c == 0 ? R : 0) : nullptr;

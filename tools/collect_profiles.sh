@@ -39,6 +39,8 @@ pmc_pass c4 $C4 || exit 1
 echo "[6] offline/online form, HMC rehearsal, full cfg4 shard"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/oo_overlapped -o run -- python $B --projection offline_online > $out/bench_oo_overlapped.log 2>&1 || exit 1
 python bench.py --workload hmc --steps 10000 --warmup 100 > $out/bench_hmc.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/hmc -o run -- python bench.py --workload hmc --steps 1000 --warmup 50 --cpu-samples 0 > $out/bench_hmc_traced.log 2>&1 || exit 1
+python tools/hmc_timeline.py $out/hmc/run_kernel_trace.csv > $out/hmc_timeline.txt 2>&1; rm -f $out/hmc/run_kernel_trace.csv
 python bench.py --steps 2 --warmup 1 --cpu-samples 0 --no-host-io --no-other --params field --m 20 --r 200 --samples 125000 > $out/bench_c4_full.log 2>&1 || exit 1
 python tools/pmc_summary.py $out > $out/summary.log 2>&1
 cat $out/summary.log
