@@ -14,6 +14,12 @@ namespace finrom {
 
 __device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
 __device__ __forceinline__ float elu_grad_f(float z) { return z > 0.f ? 1.f : expf(z); }
+// LDS hand-over between the lanes of ONE wave: LDS executes a wave's instructions in order, so all this has to stop is the compiler
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 constexpr int MLP_MAX_W = 64;        // hidden width (reference: 50 / 100 -> 64 covers load_bn_model's models; checked at create)
 constexpr int MLP_PARTS = 16;        // threads per hidden unit in the first layer (1024 threads = 64 units x 16 parts: the layer is
@@ -96,11 +102,14 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, cons
     y[tid] = m.b0[tid] + t;
   }
   __syncthreads();
+  // the layers behind the first are 50 threads' work -- wave 0's: the other fifteen waves leave, and what were workgroup barriers
+  // between the layers (sixteen waves to collect, twice per layer) are the wave's own program order
+  if (tid >= 64) return;
   float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
   for (int l = 0; l <= m.n_layers; ++l) {              // l == n_layers: the head
     const float* sc = m.scale + l * nw; const float* sh = m.shift + l * nw;
     if (tid < nw) { const float z = fmaf(y[tid], sc[tid], sh[tid]); tp[l * nw + tid] = z; a[tid] = elu_f(z); }
-    __syncthreads();
+    wave_sync();
     if (l < m.n_layers) {
       const float* W = m.W + (int64_t)l * nw * nw;
       if (tid < nw) {                                 // (weights requested 16 at a time: every load waited for on its own is a
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, cons
       e_out[s * m.n_out + tid] = (double)acc;
       if (data_shift != nullptr) data_shift[s * m.n_out + tid] = data[(data_stride ? s * data_stride : 0) + tid] - (double)acc;
     }
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
                                                            const double* __restrict__ g_theta, const double* __restrict__ Sop,
                                                            int P, double* __restrict__ grad, const double* __restrict__ g_parts,
                                                            int n_parts) {
-  __shared__ float g[MLP_MAX_W], gn[MLP_MAX_W], up[MLP_MAX_W];
+  __shared__ float g[MLP_MAX_W], up[MLP_MAX_W];
   __shared__ double gth[32];
   const int64_t s = blockIdx.x;
   const int tid = threadIdx.x, nw = m.n_w;
@@ -149,38 +158,48 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
   }
   if (tid < P) {
     double t = 0.0;
-    if (g_parts != nullptr) {                          // the contraction's partial sums, in its own fixed order
-      for (int w = 0; w < n_parts; ++w) t += g_parts[(s * n_parts + w) * 32 + tid];
+    if (g_parts != nullptr) {                          // the contraction's partial sums, in its own fixed order (requested twelve at a time)
+      for (int w0 = 0; w0 < n_parts; w0 += 12) {
+        double v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) v[u] = w0 + u < n_parts ? g_parts[(s * n_parts + w0 + u) * 32 + tid] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) t += v[u];
+      }
     } else if (g_theta != nullptr) t = g_theta[s * P + tid];
     gth[tid] = t;
   }
   __syncthreads();
-  if (tid < nw) {                                      // through the head: no skip connection
-    float acc = 0.f;
-    for (int o = 0; o < m.n_out; ++o) acc = fmaf(up[o], m.Wh[tid * m.n_out + o], acc);
-    const float z = tp[m.n_layers * nw + tid];
-    g[tid] = acc * elu_grad_f(z) * m.scale[m.n_layers * nw + tid];
-  }
-  __syncthreads();
-  for (int l = m.n_layers - 1; l >= 0; --l) {          // g <- g + (W_l g) * elu'(z_l) * s_l   (skip + branch)
-    const float* W = m.W + (int64_t)l * nw * nw;
-    if (tid < nw) {
-      float acc = 0.f;
-      int j = 0;
-      for (; j + 16 <= nw; j += 16) {
-        float wv[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) wv[u] = W[tid * nw + j + u];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc = fmaf(g[j + u], wv[u], acc);
-      }
-      for (; j < nw; ++j) acc = fmaf(g[j], W[tid * nw + j], acc);
-      gn[tid] = g[tid] + acc * elu_grad_f(tp[l * nw + tid]) * m.scale[l * nw + tid];
+  if (tid < 64) {                                      // head and hidden layers are 50 threads' work: wave 0 walks back alone, its
+    if (tid < nw) {                                    // hand-overs are its own program order (not barriers of sixteen waves)
+      float acc = 0.f;                                 // through the head: no skip connection
+      for (int o = 0; o < m.n_out; ++o) acc = fmaf(up[o], m.Wh[tid * m.n_out + o], acc);
+      const float z = tp[m.n_layers * nw + tid];
+      g[tid] = acc * elu_grad_f(z) * m.scale[m.n_layers * nw + tid];
     }
-    __syncthreads();
-    if (tid < nw) g[tid] = gn[tid];
-    __syncthreads();
+    wave_sync();
+    for (int l = m.n_layers - 1; l >= 0; --l) {        // g <- g + (W_l g) * elu'(z_l) * s_l   (skip + branch)
+      const float* W = m.W + (int64_t)l * nw * nw;
+      float gnew = 0.f;
+      if (tid < nw) {
+        float acc = 0.f;
+        int j = 0;
+        for (; j + 16 <= nw; j += 16) {
+          float wv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) wv[u] = W[tid * nw + j + u];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = fmaf(g[j + u], wv[u], acc);
+        }
+        for (; j < nw; ++j) acc = fmaf(g[j], W[tid * nw + j], acc);
+        gnew = g[tid] + acc * elu_grad_f(tp[l * nw + tid]) * m.scale[l * nw + tid];
+      }
+      wave_sync();                                     // everybody has read the old g
+      if (tid < nw) g[tid] = gnew;
+      wave_sync();
+    }
   }
+  __syncthreads();                                     // g is final: the other waves join for the first layer's transpose
   const int wg = NP > 1 ? (int)blockIdx.y : 0;
   const int r0 = (int)((int64_t)m.n_in * wg / NP), r1 = (int)((int64_t)m.n_in * (wg + 1) / NP);
   for (int i = r0 + tid; i < r1; i += MLP_THREADS) {
