@@ -233,6 +233,11 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
       });
     }
     // (a) the diagonal tile: 16 elimination steps on [T_kk | I]; M^T is carried (column operations), which is M as an A operand
+    // (This is what the sweep spends its time on: ~450 cycles per pivot, 96 pivots.  Not a latency chain -- taking the pivots off
+    // the vector update (p_{k+1} = D[k+1][k+1] - D[k+1][k]^2 / p_k from three v_readlanes, reciprocal instead of 1/sqrt on the
+    // chain) made it 6 % SLOWER -- but issue: one wave alone on its SIMD issues an instruction every >= 4 cycles and a step is
+    // ~100 of them, twelve ds_bpermutes among them.  Fewer instructions per pivot would need a 4 x 4-blocked tile
+    // factorisation with the rank-4 updates and the inverse on the matrix cores; not built.)
     double Am[4];
 #ifdef FINROM_SOLVE_CLOCKS
     const long long cd0 = wall_clock64();
