@@ -192,8 +192,8 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
         trace[0].copy_(K)
     g = None
     if graph and n_prop > 0:
+        state = [t.clone() for t in (K, U, dU, acc, jt, pt)]
         try:
-            state = [t.clone() for t in (K, U, dU, acc, jt, pt)]
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                           # warm-up on a side stream, as torch's graph recipe asks
