@@ -348,9 +348,9 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
   // meshes without window sizes (m >= 32); finrom_fom_gradient keeps it for small batches (its adjoint stage beats a lone wave
   // of the band adjoint kernel: 3.1 against 10 ms).
   if (h->small.small_max > 0 && S <= h->small.small_max && !(h->band.on && !env_no_band)) {
-    if (!(stages & 2)) return 0;
     int rc;
     if (!h->small.in_lds && (rc = h->Gw.reserve((size_t)S * d.gsize * sizeof(double)))) return rc;
+    if (!(stages & 2)) return 0;
     h->last_path = h->small.in_lds ? FINROM_FOM_PATH_SMALL_LDS : FINROM_FOM_PATH_SMALL_GLOBAL;
     return launch_fom_small(d, h->small, x, S, (double*)h->Gw.p, qoi, w, info, st);
   }
@@ -363,9 +363,11 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
     for (int64_t s0 = 0; s0 < S; s0 += chunk) {
       const int64_t Sc = std::min(chunk, S - s0), nblk = (Sc + 63) / 64;
       int rc;
-      if (stages & 1) {
+      if (stages & (1 | 4)) {                            // (4: reserve the workspace only -- finrom_solve_pairs, before its fork)
         if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
         if ((rc = h->Gw.reserve((size_t)nblk * b.gsize * 64 * sizeof(double)))) return rc;
+      }
+      if (stages & 1) {
         if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
         if ((rc = launch_fom_assemble(h->band_asm, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
       }
@@ -384,9 +386,11 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
     const int64_t Sc = std::min(chunk, S - s0);
     const int64_t nblk = (Sc + 63) / 64;
     int rc;
-    if (stages & 1) {
+    if (stages & (1 | 4)) {
       if ((rc = h->xT.reserve((size_t)nblk * d.xdim * 64 * sizeof(double)))) return rc;
       if ((rc = h->Gw.reserve((size_t)nblk * d.gsize * 64 * sizeof(double)))) return rc;
+    }
+    if (stages & 1) {
       if ((rc = launch_pack(x + s0 * d.xdim, Sc, d.xdim, (double*)h->xT.p, st))) return rc;
       if (!d.fused && (rc = launch_fom_assemble(d, (const double*)h->xT.p, nblk, (double*)h->Gw.p, st))) return rc;
     }
@@ -1365,8 +1369,10 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   // (the fork below: everything already queued on the caller's stream -- inputs, zeroed info -- precedes both halves)
   // ROM half first, on a high-priority stream: its 4-wave, 160-VGPR workgroups need large contiguous
   // register ranges, so they claim their slots before the small FOM waves fill the remaining ones
-  // The FOM's short bandwidth-bound pre-pass (pack + assembly) runs first, alone; beside the projection kernel it
-  // would crawl and hold back the interpreter, whose waves then start late.
+  // The FOM's short bandwidth-bound pre-pass (pack + assembly) used to run first, alone: beside the projection kernel it crawls and
+  // the interpreter of round 1, whose waves then started late, WAS the critical path.  Since the band sweep the FOM half ends
+  // long before the ROM half (6.8 against 21.8 ms side by side at the headline), so the pre-pass now runs after the fork, on the
+  // FOM side, and only the sub-fin averages -- the head of the ROM half -- precede it.
   // Every workspace the two halves need is reserved BEFORE the fork: an allocation failure after it would return while the
   // side stream still writes the caller's outputs.  Any other failure after the fork joins the side stream first.
   const bool split = S <= fom_chunk_samples(fom->d, &fom->band);
@@ -1374,16 +1380,16 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     if (overlap && hipEventRecord(rom->ev_join, side) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join, 0);
   };
   auto fail = [&](int code) { if (overlap) (void)hipStreamSynchronize(side); return code; };
-  if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return rc;          // (reserves the FOM workspace)
+  if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 4))) return rc;          // (reserves the FOM workspace)
   // the sub-fin averages (bandwidth-bound, short) run BEFORE the fork, alone: beside the sweep they were starved (0.19 -> 0.39 ms
   // at the headline, 0.6 -> 5.8 ms at m = 20) and they head the ROM half's critical path
   if ((rc = launch_subfin_avg(Sop, rom->d.P, fom->d.xdim, x, S, theta, st))) return fail(rc);
-  if (overlap) {                          // the ROM half starts after the pre-pass and the averages
+  if (overlap) {                          // the ROM half starts after the averages
     FR_HIP(hipEventRecord(rom->ev_fork, st));
     FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
   }
   if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return fail(rc);
-  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, split ? 2 : 3))) return fail(rc);
+  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 3))) return fail(rc);
   join();
   if (err && (rc = launch_sub(qoi, qoi_r, S * (int64_t)fom->d.n_obs, err, st))) return rc;
   if (tracing) {

@@ -27,9 +27,35 @@ __global__ __launch_bounds__(256) void subfin_avg_kernel(const double* __restric
   }
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
-    double x = acc[p];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-    if (lane == 0 && p < P) theta[s * P + p] = x;
+    if (p < P) {                                         // (wave-uniform: the unused sums are not reduced)
+      double x = acc[p];
+      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+      if (lane == 0) theta[s * P + p] = x;
+    }
+  }
+}
+
+// The same product for parameter vectors (n = 5 / 9 conductivities per sample, the dataset loop's five- and nine-parameter forms):
+// a wave per sample would spend its time reducing 64 lanes of which n are busy (0.2 ms per 100k samples at the head of the ROM
+// half's critical path) -- here a thread owns a sample, S (P x n doubles) sits in LDS, sums run over j in index order.
+constexpr int SUBFIN_SMALL_N = 16;
+__global__ __launch_bounds__(256) void subfin_avg_small_kernel(const double* __restrict__ Sop, int P, int n,
+                                                               const double* __restrict__ k, int64_t S,
+                                                               double* __restrict__ theta) {
+  __shared__ double sl[MAXP * SUBFIN_SMALL_N];
+  for (int t = threadIdx.x; t < P * n; t += 256) sl[t] = Sop[t];
+  __syncthreads();
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  double kv[SUBFIN_SMALL_N];
+#pragma unroll
+  for (int j = 0; j < SUBFIN_SMALL_N; ++j) kv[j] = j < n ? k[s * n + j] : 0.0;
+  for (int p = 0; p < P; ++p) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < SUBFIN_SMALL_N; ++j)
+      if (j < n) acc = fma(sl[p * n + j], kv[j], acc);
+    theta[s * P + p] = acc;
   }
 }
 
@@ -37,7 +63,10 @@ int launch_subfin_avg(const double* Sop, int P, int n, const double* k, int64_t 
   if (S == 0) return 0;
   if (P > MAXP) { set_error("subfin_avg: P > 16"); return FINROM_ERR_UNSUPPORTED; }
   ScopedKernelTimer t(K_AVG, st);
-  hipLaunchKernelGGL(subfin_avg_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, Sop, P, n, k, S, theta);
+  if (n <= SUBFIN_SMALL_N)
+    hipLaunchKernelGGL(subfin_avg_small_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, Sop, P, n, k, S, theta);
+  else
+    hipLaunchKernelGGL(subfin_avg_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, Sop, P, n, k, S, theta);
   FR_HIP(hipGetLastError());
   return 0;
 }
