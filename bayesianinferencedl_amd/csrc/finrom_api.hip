@@ -112,6 +112,7 @@ struct finrom_rom_s {
   }
   // finrom_romml_grad -> finrom_rom_grad (one-sample form only): leave the gradient's partial sums to the consumer; where they are
   bool defer_gsum = false; const double* last_gpart = nullptr;
+  const MlpFuse* fuse = nullptr;       // (same path) the error model's forward pass as a workgroup of the contraction kernel
 };
 struct finrom_sampler_s { double* U = nullptr; int n = 0; Scratch xi; };
 struct finrom_mlp_s { MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp; };
@@ -1266,7 +1267,7 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
       ga.defer_sum = h->defer_gsum && s0 == 0 && Sc == S;
       h->last_gpart = ga.defer_sum ? ga.gpart : nullptr;
       if ((rc = launch_rom_onesample(d, theta + s0 * d.P, Sc, (double*)h->part.p, 1, ga, w_r ? w_r + s0 * d.r : nullptr, q,
-                                     info ? info + s0 : nullptr, st))) return rc;
+                                     info ? info + s0 : nullptr, st, ga.defer_sum ? h->fuse : nullptr))) return rc;
       if ((rc = launch_rom_grad_contract_small(d, Sc, ga, st))) return rc;
       continue;
     }
@@ -1484,7 +1485,7 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
   const int P = rom->d.P, no = m.n_out;
   int rc;
   if ((rc = mlp->tape.reserve((size_t)S * (m.n_layers + 1) * m.n_w * sizeof(float)))) return rc;
-  if ((rc = mlp->theta.reserve((size_t)S * P * sizeof(double)))) return rc;
+  if ((rc = mlp->theta.reserve(((size_t)S * P + (size_t)S * 16 * 16) * sizeof(double)))) return rc;      // theta | the contraction workgroups' own copies (MlpFuse)
   if ((rc = mlp->gth.reserve((size_t)S * P * sizeof(double)))) return rc;
   if ((rc = mlp->shift.reserve((size_t)S * no * sizeof(double)))) return rc;
   if (!qoi_r) { if ((rc = mlp->qtmp.reserve((size_t)S * no * sizeof(double)))) return rc; qoi_r = (double*)mlp->qtmp.p; }
@@ -1492,24 +1493,34 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
   const int64_t stride = data_per_sample ? no : 0;
   // (the sub-fin averages theta = S k are formed inside the network's forward kernel: it reads k anyway)
   // One-sample form (the ROM's contraction + solve kernels, S <= 64): the gradient contraction leaves its partial sums to the
-  // error model's backward kernel instead of fencing and drawing tickets for a last workgroup (-7 us per call).
+  // error model's backward kernel instead of fencing and drawing tickets for a last workgroup (-7 us per call); the error
+  // model's forward pass is one more workgroup per sample of the ROM's contraction kernel (MlpFuse), behind the sub-fin averages.
   // (Tried and removed: under stream capture, the error model's forward kernel on a side stream beside the ROM's contraction
   // kernel -- the solve kernel is the first to need its output.  One fork / join inside a replayed graph cost ~240 us per call
   // on this runtime: 113 -> 355 us, tools/graph_call_cost.py.)
   const bool one = rom->projection == FINROM_PROJECTION_DIRECT && rom_onesample_applies(rom->d, S) && getenv("FINROM_OLD_SUBST") == nullptr &&
                    rom->g_npairs > 0;
-  if (P <= 16) {
+  MlpFuse fm;
+  if (one && P <= 16) {                                // the network's forward pass and theta = S k ride in the ROM's contraction kernel
+    fm.on = 1; fm.m = m; fm.k = k; fm.data = data; fm.data_stride = stride; fm.tape = (float*)mlp->tape.p; fm.e_out = e_nn;
+    fm.data_shift = (double*)mlp->shift.p;
+    fm.Sop = Sop; fm.P = P; fm.theta_out = (double*)mlp->theta.p; fm.theta_scr = (double*)mlp->theta.p + (size_t)S * P;
+  } else if (P <= 16) {
     if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st, Sop, P, (double*)mlp->theta.p))) return rc;
   } else {
     if ((rc = launch_subfin_avg(Sop, P, m.n_in, k, S, (double*)mlp->theta.p, st))) return rc;
     if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st))) return rc;
   }
-  rom->defer_gsum = one; rom->last_gpart = nullptr;
+  rom->defer_gsum = one; rom->last_gpart = nullptr; rom->fuse = fm.on ? &fm : nullptr;
   rc = finrom_rom_grad(rom, (const double*)mlp->theta.p, (const double*)mlp->shift.p, 1, S, loss, (double*)mlp->gth.p, nullptr,
                        qoi_r, info, st);
   const double* gparts = rom->last_gpart;
-  rom->defer_gsum = false; rom->last_gpart = nullptr;
+  rom->defer_gsum = false; rom->last_gpart = nullptr; rom->fuse = nullptr;
   if (rc) return rc;
+  if (fm.on && gparts == nullptr) {                    // (the predicate above and finrom_rom_grad's own must agree)
+    set_error("romml_grad: internal: the one-sample form was announced but not taken");
+    return FINROM_ERR_UNSUPPORTED;
+  }
   return launch_mlp_backward(m, S, (const float*)mlp->tape.p, data, stride, qoi_r, e_nn, (const double*)mlp->gth.p, Sop, P, grad, st,
                              gparts, gparts ? ROM_GRAD_SMALL_NG : 0);
 }

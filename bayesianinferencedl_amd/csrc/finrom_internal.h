@@ -190,6 +190,18 @@ struct MlpDev {
   const float* W; const float* b;              // [n_layers x n_w x n_w], [n_layers x n_w]
   const float* Wh; const float* bh;            // [n_w x n_out], [n_out]
 };
+// the error model's forward pass riding as ONE MORE workgroup per sample in rom_small_proj_kernel (finrom_romml_grad's one-sample
+// form: the ROM's contraction does not depend on it, the solve kernel behind both is the first to need its output)
+struct MlpFuse {
+  int on = 0;
+  MlpDev m{};
+  const double* k = nullptr; const double* data = nullptr; int64_t data_stride = 0;
+  float* tape = nullptr; double* e_out = nullptr; double* data_shift = nullptr;
+  // the sub-fin averages theta = S k too: every contraction workgroup forms its sample's theta itself (the same sums in the
+  // same order, into its own 16 doubles of theta_scr [S x NC x 16], which its scalar loads then read), workgroup 0 also writes
+  // theta_out [S x P] for the kernels behind
+  const double* Sop = nullptr; int P = 0; double* theta_scr = nullptr; double* theta_out = nullptr;
+};
 int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double* data, int64_t data_stride, float* tape,
                        double* e_out, double* data_shift, hipStream_t st, const double* Sop = nullptr, int P = 0,
                        double* theta_out = nullptr);
@@ -266,7 +278,7 @@ bool rom_splitk_applies(const RomDev& p, int64_t S);
 bool rom_onesample_applies(const RomDev& p, int64_t S);
 size_t rom_onesample_scratch_bytes(const RomDev& p, int64_t S);
 int launch_rom_onesample(const RomDev& p, const double* theta, int64_t S, double* part, int grad, const RomGradArgs& ga, double* w_r,
-                         double* qoi_r, int* info, hipStream_t st);
+                         double* qoi_r, int* info, hipStream_t st, const MlpFuse* fuse = nullptr);
 constexpr int ROM_GRAD_SMALL_NG = 36;      // blocks per sample in rom_grad_contract_small_kernel
 int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st);
 int launch_rom_proj_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,

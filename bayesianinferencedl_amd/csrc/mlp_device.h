@@ -1,0 +1,139 @@
+// Device pieces of the learned error model shared by mlp_kernels.hip (one workgroup of 1024 threads per sample) and
+// rom_onesample.hip (the network's forward pass as a spare 256-thread workgroup of the reduced model's contraction kernel):
+// see mlp_kernels.hip for the model.
+#pragma once
+#include "finrom_internal.h"
+
+namespace finrom {
+
+__device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
+__device__ __forceinline__ float elu_grad_f(float z) { return z > 0.f ? 1.f : expf(z); }
+// LDS hand-over between the lanes of ONE wave: LDS executes a wave's instructions in order, so all this has to stop is the compiler
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int MLP_MAX_W = 64;        // hidden width (reference: 50 / 100 -> 64 covers load_bn_model's models; checked at create)
+
+// e_out[s][o] (double) = network output; data_shift[s][o] = data[o] - e_out (what the ROM adjoint is run against)
+// (Sop, P, theta_out: when given, the sub-fin averages theta = S k of the same field (fom/forward_solve.py:466-480) are formed here
+// in fp64 while k is being read anyway -- one launch less in the one-sample call chain of finrom_romml_grad)
+// (NTHR threads of ONE workgroup, sample s; xs: n_in floats of LDS.  NTHR = 1024 in mlp_forward_kernel; 256 where the network rides in
+// a spare workgroup of the reduced model's contraction kernel, rom_onesample.hip.)
+template <int NTHR>
+__device__ __forceinline__ void mlp_forward_body(const MlpDev& m, const double* __restrict__ k, int64_t s,
+                                                 const double* __restrict__ data, int64_t data_stride,
+                                                 float* __restrict__ tape, double* __restrict__ e_out,
+                                                 double* __restrict__ data_shift, const double* __restrict__ Sop, int P,
+                                                 double* __restrict__ theta_out, float* __restrict__ xs, int tid) {
+  constexpr int MLP_PARTS = NTHR / 64;                 // threads per hidden unit in the first layer
+  constexpr int MLP_THREADS = NTHR;
+  constexpr int CH = NTHR >= 1024 ? 32 : 128;          // first-layer loads in flight per thread (fewer threads: deeper batches)
+  __shared__ float part[MLP_PARTS][MLP_MAX_W];
+  __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
+  __shared__ double tred[MLP_PARTS];
+  const int nw = m.n_w;
+  for (int i = tid; i < m.n_in; i += MLP_THREADS) xs[i] = (float)k[s * m.n_in + i];
+  if (theta_out != nullptr) {
+    // theta_p = sum_i Sop[p][i] k[i] in fp64: row p belongs to the waves p WPR .. p WPR + WPR - 1 (WPR = 16 / P: three waves per row
+    // for five averages), a wave's slice dealt over its lanes in coalesced passes of 64, 13 passes requested at a time; ONE
+    // value per wave to reduce across lanes.  (The first version had every thread carry all 16 partial sums through the input
+    // loop and every wave reduce all of them: 16 x 6 shuffles of doubles per wave, 11.8 of the kernel's 25 us; now 4.6.)
+    const int wave = tid >> 6, lane = tid & 63, WPR = MLP_PARTS / P > 0 ? MLP_PARTS / P : 1, p = wave / WPR, part_ = wave - p * WPR;
+    double v = 0.0;
+    if (p < P) {
+      const int i0 = (int)((int64_t)m.n_in * part_ / WPR), i1 = (int)((int64_t)m.n_in * (part_ + 1) / WPR);
+      const double* __restrict__ srow = Sop + (int64_t)p * m.n_in;
+      const double* __restrict__ krow = k + s * m.n_in;
+      double v2 = 0.0;
+      for (int i = i0 + lane; i < i1; i += 64 * 13) {
+        double sv[13], kv[13];
+#pragma unroll
+        for (int u = 0; u < 13; ++u) { const int ii = i + 64 * u; const bool ok = ii < i1; sv[u] = ok ? srow[ii] : 0.0; kv[u] = ok ? krow[ii] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 13; ++u) { if (u & 1) v2 = fma(sv[u], kv[u], v2); else v = fma(sv[u], kv[u], v); }
+      }
+      v += v2;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    }
+    if (lane == 0) tred[wave] = v;
+  }
+  __syncthreads();
+  if (theta_out != nullptr && tid < P) {               // the row's waves in a fixed order
+    const int WPR = MLP_PARTS / P;
+    double t = 0.0;
+    for (int wv = 0; wv < WPR; ++wv) t += tred[tid * WPR + wv];
+    theta_out[s * P + tid] = t;
+  }
+  {                                                   // y0 = W0^T x + b0: unit j = tid % 64, part p = tid / 64 of the rows
+    const int j = tid & 63, p = tid >> 6;
+    float acc = 0.f;
+    if (j < nw) {
+      const int i0 = (int)((int64_t)m.n_in * p / MLP_PARTS), i1 = (int)((int64_t)m.n_in * (p + 1) / MLP_PARTS);
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};              // four independent chains, CH loads in flight
+      int i = i0;
+      for (; i + CH <= i1; i += CH) {
+        float wv[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) wv[u] = m.W0[(int64_t)(i + u) * nw + j];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) a4[u & 3] = fmaf(xs[i + u], wv[u], a4[u & 3]);
+      }
+      if constexpr (CH > 16) {                         // (the tail in one clamped batch of 16 where the batches are deep)
+        for (; i + 16 <= i1; i += 16) {
+          float wv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) wv[u] = m.W0[(int64_t)(i + u) * nw + j];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) a4[u & 3] = fmaf(xs[i + u], wv[u], a4[u & 3]);
+        }
+      }
+      for (; i < i1; ++i) a4[0] = fmaf(xs[i], m.W0[(int64_t)i * nw + j], a4[0]);
+      acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    }
+    part[p][j] = acc;
+  }
+  __syncthreads();
+  if (tid < nw) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < MLP_PARTS; ++w) t += part[w][tid];
+    y[tid] = m.b0[tid] + t;
+  }
+  __syncthreads();
+  // the layers behind the first are 50 threads' work -- wave 0's: the other fifteen waves leave, and what were workgroup barriers
+  // between the layers (sixteen waves to collect, twice per layer) are the wave's own program order
+  if (tid >= 64) return;
+  float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
+  for (int l = 0; l <= m.n_layers; ++l) {              // l == n_layers: the head
+    const float* sc = m.scale + l * nw; const float* sh = m.shift + l * nw;
+    if (tid < nw) { const float z = fmaf(y[tid], sc[tid], sh[tid]); tp[l * nw + tid] = z; a[tid] = elu_f(z); }
+    wave_sync();
+    if (l < m.n_layers) {
+      const float* W = m.W + (int64_t)l * nw * nw;
+      if (tid < nw) {                                 // (weights requested 16 at a time: every load waited for on its own is a
+        float acc = m.b[l * nw + tid];                 //  trip to L2 on the critical path of a one-sample call)
+        int i = 0;
+        for (; i + 16 <= nw; i += 16) {
+          float wv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) wv[u] = W[(i + u) * nw + tid];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = fmaf(a[i + u], wv[u], acc);
+        }
+        for (; i < nw; ++i) acc = fmaf(a[i], W[i * nw + tid], acc);
+        y[tid] += acc;
+      }
+    } else if (tid < m.n_out) {
+      float acc = m.bh[tid];
+      for (int i = 0; i < nw; ++i) acc = fmaf(a[i], m.Wh[i * m.n_out + tid], acc);
+      e_out[s * m.n_out + tid] = (double)acc;
+      if (data_shift != nullptr) data_shift[s * m.n_out + tid] = data[(data_stride ? s * data_stride : 0) + tid] - (double)acc;
+    }
+    wave_sync();
+  }
+}
+
+}  // namespace finrom

@@ -8,20 +8,10 @@
 // first layer split over 16 threads per hidden unit, the 50 x 50 layers one thread per output.  Forward keeps the pre-activations
 // ("tape", (L + 1) x n_w floats per sample) for the backward kernel, which runs after the ROM adjoint (its upstream is the
 // residual data - (qoi_r + e_NN)) and also adds the ROM part g_theta^T S, so that the final gradient is written once.
-#include "finrom_internal.h"
+#include "mlp_device.h"
 
 namespace finrom {
 
-__device__ __forceinline__ float elu_f(float z) { return z > 0.f ? z : expm1f(z); }
-__device__ __forceinline__ float elu_grad_f(float z) { return z > 0.f ? 1.f : expf(z); }
-// LDS hand-over between the lanes of ONE wave: LDS executes a wave's instructions in order, so all this has to stop is the compiler
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-constexpr int MLP_MAX_W = 64;        // hidden width (reference: 50 / 100 -> 64 covers load_bn_model's models; checked at create)
 constexpr int MLP_PARTS = 16;        // threads per hidden unit in the first layer (1024 threads = 64 units x 16 parts: the layer is
                                      // 1597 x 50 dependent-load multiply-adds per sample and the call is latency-bound -- 100 rows
                                      // per thread, 32 loads in flight, instead of 400 rows with 4 parts: 28 -> ~10 us)
@@ -29,110 +19,13 @@ constexpr int MLP_THREADS = 64 * MLP_PARTS;
 constexpr int MLP_SPLIT = 8;         // workgroups per sample in the backward kernel's one-sample form ...
 constexpr int MLP_SPLIT_MAX_S = 64;  // ... which serves calls of up to this many samples
 
-// e_out[s][o] (double) = network output; data_shift[s][o] = data[o] - e_out (what the ROM adjoint is run against)
-// (Sop, P, theta_out: when given, the sub-fin averages theta = S k of the same field (fom/forward_solve.py:466-480) are formed here
-// in fp64 while k is being read anyway -- one launch less in the one-sample call chain of finrom_romml_grad)
 __global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, const double* __restrict__ k, int64_t S,
                                                           const double* __restrict__ data, int64_t data_stride,
                                                           float* __restrict__ tape, double* __restrict__ e_out,
                                                           double* __restrict__ data_shift, const double* __restrict__ Sop, int P,
                                                           double* __restrict__ theta_out) {
-  extern __shared__ float xs[];                        // [n_in] input, then scratch
-  __shared__ float part[MLP_PARTS][MLP_MAX_W];
-  __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
-  __shared__ double tred[MLP_PARTS];
-  const int64_t s = blockIdx.x;
-  const int tid = threadIdx.x, nw = m.n_w;
-  for (int i = tid; i < m.n_in; i += MLP_THREADS) xs[i] = (float)k[s * m.n_in + i];
-  if (theta_out != nullptr) {
-    // theta_p = sum_i Sop[p][i] k[i] in fp64: row p belongs to the waves p WPR .. p WPR + WPR - 1 (WPR = 16 / P: three waves per row
-    // for five averages), a wave's slice dealt over its lanes in coalesced passes of 64, 13 passes requested at a time; ONE
-    // value per wave to reduce across lanes.  (The first version had every thread carry all 16 partial sums through the input
-    // loop and every wave reduce all of them: 16 x 6 shuffles of doubles per wave, 11.8 of the kernel's 25 us; now 4.6.)
-    const int wave = tid >> 6, lane = tid & 63, WPR = MLP_PARTS / P, p = wave / WPR, part_ = wave - p * WPR;
-    double v = 0.0;
-    if (p < P) {
-      const int i0 = (int)((int64_t)m.n_in * part_ / WPR), i1 = (int)((int64_t)m.n_in * (part_ + 1) / WPR);
-      const double* __restrict__ srow = Sop + (int64_t)p * m.n_in;
-      const double* __restrict__ krow = k + s * m.n_in;
-      double v2 = 0.0;
-      for (int i = i0 + lane; i < i1; i += 64 * 13) {
-        double sv[13], kv[13];
-#pragma unroll
-        for (int u = 0; u < 13; ++u) { const int ii = i + 64 * u; const bool ok = ii < i1; sv[u] = ok ? srow[ii] : 0.0; kv[u] = ok ? krow[ii] : 0.0; }
-#pragma unroll
-        for (int u = 0; u < 13; ++u) { if (u & 1) v2 = fma(sv[u], kv[u], v2); else v = fma(sv[u], kv[u], v); }
-      }
-      v += v2;
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    }
-    if (lane == 0) tred[wave] = v;
-  }
-  __syncthreads();
-  if (theta_out != nullptr && tid < P) {               // the row's waves in a fixed order
-    const int WPR = MLP_PARTS / P;
-    double t = 0.0;
-    for (int wv = 0; wv < WPR; ++wv) t += tred[tid * WPR + wv];
-    theta_out[s * P + tid] = t;
-  }
-  {                                                   // y0 = W0^T x + b0: unit j = tid % 64, part p = tid / 64 of the rows
-    const int j = tid & 63, p = tid >> 6;
-    float acc = 0.f;
-    if (j < nw) {
-      const int i0 = (int)((int64_t)m.n_in * p / MLP_PARTS), i1 = (int)((int64_t)m.n_in * (p + 1) / MLP_PARTS);
-      float a4[4] = {0.f, 0.f, 0.f, 0.f};              // four independent chains, eight loads in flight each
-      int i = i0;
-      for (; i + 32 <= i1; i += 32) {
-        float wv[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) wv[u] = m.W0[(int64_t)(i + u) * nw + j];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) a4[u & 3] = fmaf(xs[i + u], wv[u], a4[u & 3]);
-      }
-      for (; i < i1; ++i) a4[0] = fmaf(xs[i], m.W0[(int64_t)i * nw + j], a4[0]);
-      acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-    }
-    part[p][j] = acc;
-  }
-  __syncthreads();
-  if (tid < nw) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < MLP_PARTS; ++w) t += part[w][tid];
-    y[tid] = m.b0[tid] + t;
-  }
-  __syncthreads();
-  // the layers behind the first are 50 threads' work -- wave 0's: the other fifteen waves leave, and what were workgroup barriers
-  // between the layers (sixteen waves to collect, twice per layer) are the wave's own program order
-  if (tid >= 64) return;
-  float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
-  for (int l = 0; l <= m.n_layers; ++l) {              // l == n_layers: the head
-    const float* sc = m.scale + l * nw; const float* sh = m.shift + l * nw;
-    if (tid < nw) { const float z = fmaf(y[tid], sc[tid], sh[tid]); tp[l * nw + tid] = z; a[tid] = elu_f(z); }
-    wave_sync();
-    if (l < m.n_layers) {
-      const float* W = m.W + (int64_t)l * nw * nw;
-      if (tid < nw) {                                 // (weights requested 16 at a time: every load waited for on its own is a
-        float acc = m.b[l * nw + tid];                 //  trip to L2 on the critical path of a one-sample call)
-        int i = 0;
-        for (; i + 16 <= nw; i += 16) {
-          float wv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) wv[u] = W[(i + u) * nw + tid];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc = fmaf(a[i + u], wv[u], acc);
-        }
-        for (; i < nw; ++i) acc = fmaf(a[i], W[i * nw + tid], acc);
-        y[tid] += acc;
-      }
-    } else if (tid < m.n_out) {
-      float acc = m.bh[tid];
-      for (int i = 0; i < nw; ++i) acc = fmaf(a[i], m.Wh[i * m.n_out + tid], acc);
-      e_out[s * m.n_out + tid] = (double)acc;
-      if (data_shift != nullptr) data_shift[s * m.n_out + tid] = data[(data_stride ? s * data_stride : 0) + tid] - (double)acc;
-    }
-    wave_sync();
-  }
+  extern __shared__ float xs[];                        // [n_in] input
+  mlp_forward_body<MLP_THREADS>(m, k, (int64_t)blockIdx.x, data, data_stride, tape, e_out, data_shift, Sop, P, theta_out, xs, (int)threadIdx.x);
 }
 
 // grad[s][i] = sum_p g_theta[s][p] Sop[p][i]  -  sum_j g0[j] W0[i][j],  g0 = d(1/2 |r|^2)/d(y0) with upstream r = data - (qoi_r + e)

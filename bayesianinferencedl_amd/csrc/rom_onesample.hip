@@ -20,6 +20,7 @@
 //     backward  ONE block substitution for both right-hand sides: X_kb = M_kb^T (R_kb - sum_{j > kb} U(kb, j) X_j); M_kb in its
 //               C/D layout IS the A operand of M_kb^T R, U(kb, j) is read from LDS transposed.  w_r = X[:, 0], v_r = X[:, 1].
 #include "rom_proj_device.h"
+#include "mlp_device.h"
 
 namespace finrom {
 
@@ -30,13 +31,70 @@ template <int NB> constexpr int onesample_nt() { return NB * (NB + 1) / 2; }
 // ---- contraction: partial block triangle of workgroup (s, j) ---------------------------------------------------------------------
 template <int NB>
 __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S, int NC,
-                                                                double* __restrict__ part, const int* __restrict__ kpat) {
+                                                                double* __restrict__ part, const int* __restrict__ kpat, MlpFuse fm) {
   constexpr int NT = onesample_nt<NB>();
   extern __shared__ __attribute__((aligned(16))) double red_lds[];      // 3 partial triangles: NT x 256 doubles each
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t s = blockIdx.x;
   const int j = blockIdx.y;
+  // workgroup NC of a sample (finrom_romml_grad only): the learned error model's forward pass, which this contraction does not
+  // depend on -- as a kernel of its own it was 19 us at the head of the one-sample call, here it ends with the contraction
+  if (fm.on && j == NC) {
+    mlp_forward_body<256>(fm.m, fm.k, s, fm.data, fm.data_stride, fm.tape, fm.e_out, fm.data_shift, nullptr, 0, nullptr,
+                          (float*)red_lds, (int)threadIdx.x);
+    return;
+  }
   const int q = lane >> 4, c = lane & 15;
+  if (fm.on) {
+    // theta_p = sum_i S[p][i] k[i] for this sample, by this workgroup itself (every workgroup of the sample: same sums, same order):
+    // a wave takes a quarter of the columns for ALL rows, every load of its slice requested at once; the four partial sums in a fixed
+    // order.  The result goes to the workgroup's own 16 doubles of scratch, from where the main loop's scalar loads read it
+    // (stores acknowledged by L2, then the scalar cache invalidated).
+    __shared__ double th_part[4][16];
+    const int n = fm.m.n_in, P = fm.P;
+    const double* __restrict__ krow = fm.k + s * (int64_t)n;
+    const int i0 = (int)((int64_t)n * wave / 4), i1 = (int)((int64_t)n * (wave + 1) / 4);
+    double tacc[16];
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp) tacc[pp] = 0.0;
+    constexpr int TU = 7;                                // 7 x 64 columns per pass: one pass covers a quarter of 1597
+    for (int ib = i0 + lane; ib < i1; ib += 64 * TU) {
+      double kv[TU], sv[16][TU];
+#pragma unroll
+      for (int u = 0; u < TU; ++u) kv[u] = ib + 64 * u < i1 ? krow[ib + 64 * u] : 0.0;
+#pragma unroll
+      for (int pp = 0; pp < 16; ++pp)
+        if (pp < P) {
+#pragma unroll
+          for (int u = 0; u < TU; ++u) sv[pp][u] = ib + 64 * u < i1 ? fm.Sop[(int64_t)pp * n + ib + 64 * u] : 0.0;
+        }
+#pragma unroll
+      for (int pp = 0; pp < 16; ++pp)
+        if (pp < P) {
+#pragma unroll
+          for (int u = 0; u < TU; ++u) tacc[pp] = fma(sv[pp][u], kv[u], tacc[pp]);
+        }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp)
+      if (pp < P) {
+        double x = tacc[pp];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) th_part[wave][pp] = x;
+      }
+    __syncthreads();
+    double* __restrict__ tscr = fm.theta_scr + (s * NC + j) * 16;
+    if ((int)threadIdx.x < P) {
+      const int pp = threadIdx.x;
+      const double t = ((th_part[0][pp] + th_part[1][pp]) + th_part[2][pp]) + th_part[3][pp];
+      tscr[pp] = t;
+      if (j == 0) fm.theta_out[s * P + pp] = t;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
+    theta = tscr - s * p.P;                              // (the pointer arithmetic below adds s P back)
+  }
   const unsigned long long ta = (unsigned long long)(theta + s * p.P);
   const double* theta_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ta >> 32)) << 32) |
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));
@@ -370,8 +428,11 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
 
 template <int NB>
 int launch_small(const RomDev& p, const double* theta, int64_t S, int NC, double* part, int grad, const RomGradArgs& ga, double* w_r,
-                 double* qoi_r, int* info, hipStream_t st) {
+                 double* qoi_r, int* info, hipStream_t st, const MlpFuse* fuse) {
   constexpr int lds_a = 3 * onesample_nt<NB>() * 256 * (int)sizeof(double), lds_b = small_solve_lds<NB>() * (int)sizeof(double);
+  MlpFuse fm{};
+  if (fuse != nullptr && fuse->on && (size_t)fuse->m.n_in * sizeof(float) <= (size_t)lds_a) fm = *fuse;      // (its input in the same LDS)
+  else if (fuse != nullptr && fuse->on) { set_error("rom_onesample: error model input does not fit the contraction's LDS"); return FINROM_ERR_UNSUPPORTED; }
   static PerDeviceOnce once;
   if (int rc = once.run([&]() -> int {
         FR_HIP(hipFuncSetAttribute((const void*)rom_small_proj_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
@@ -379,7 +440,8 @@ int launch_small(const RomDev& p, const double* theta, int64_t S, int NC, double
         return 0; })) return rc;
   {
     ScopedKernelTimer t(K_ROM_PROJ, st);
-    hipLaunchKernelGGL(rom_small_proj_kernel<NB>, dim3((unsigned)S, (unsigned)NC), dim3(256), lds_a, st, p, theta, S, NC, part, p.kmeta);
+    hipLaunchKernelGGL(rom_small_proj_kernel<NB>, dim3((unsigned)S, (unsigned)(NC + (fm.on ? 1 : 0))), dim3(256), lds_a, st, p, theta, S, NC, part,
+                       p.kmeta, fm);
     FR_HIP(hipGetLastError());
   }
   ScopedKernelTimer t(K_ROM_SOLVE, st);
@@ -409,11 +471,11 @@ bool rom_onesample_applies(const RomDev& p, int64_t S) {
 
 // grad = 0: w_r (optional) and qoi_r; grad = 1 (ga.data, ga.vw, ga.J set): also v_r; v_r | w_r go to ga.vw for the contraction kernel
 int launch_rom_onesample(const RomDev& p, const double* theta, int64_t S, double* part, int grad, const RomGradArgs& ga, double* w_r,
-                         double* qoi_r, int* info, hipStream_t st) {
+                         double* qoi_r, int* info, hipStream_t st, const MlpFuse* fuse) {
   if (S == 0) return 0;
   const int NC = rom_onesample_parts(p, S);
   switch (p.NB) {
-#define FR_ONE(N) case N: return launch_small<N>(p, theta, S, NC, part, grad, ga, w_r, qoi_r, info, st);
+#define FR_ONE(N) case N: return launch_small<N>(p, theta, S, NC, part, grad, ga, w_r, qoi_r, info, st, fuse);
     FR_ONE(1) FR_ONE(2) FR_ONE(3) FR_ONE(4) FR_ONE(5) FR_ONE(6)
 #undef FR_ONE
     default: set_error("rom_onesample: basis size"); return FINROM_ERR_UNSUPPORTED;

@@ -20,7 +20,7 @@ def short(n):
 dur = defaultdict(list)
 for r in rows:
     dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-steps = max(len(v) for k, v in dur.items() if "finrom::mlp_forward" in k)
+steps = max(len(v) for k, v in dur.items() if "finrom::mlp_backward" in k)
 lib = tor = 0.0
 print(f"{steps} leapfrog steps in the trace")
 for k, v in sorted(dur.items(), key=lambda kv: -len(kv[1])):
