@@ -113,9 +113,10 @@ struct finrom_rom_s {
   // finrom_romml_grad -> finrom_rom_grad (one-sample form only): leave the gradient's partial sums to the consumer; where they are
   bool defer_gsum = false; const double* last_gpart = nullptr;
   const MlpFuse* fuse = nullptr;       // (same path) the error model's forward pass as a workgroup of the contraction kernel
+  const MlpBackFuse* back = nullptr;   // (same path) its walk back through the hidden layers as a workgroup of the gradient contraction
 };
 struct finrom_sampler_s { double* U = nullptr; int n = 0; Scratch xi; };
-struct finrom_mlp_s { MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp; };
+struct finrom_mlp_s { MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp, g0; };
 
 template <class T>
 static int up(std::vector<void*>& owned, const T** dst, const T* host, size_t count) {
@@ -1268,7 +1269,7 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
       h->last_gpart = ga.defer_sum ? ga.gpart : nullptr;
       if ((rc = launch_rom_onesample(d, theta + s0 * d.P, Sc, (double*)h->part.p, 1, ga, w_r ? w_r + s0 * d.r : nullptr, q,
                                      info ? info + s0 : nullptr, st, ga.defer_sum ? h->fuse : nullptr))) return rc;
-      if ((rc = launch_rom_grad_contract_small(d, Sc, ga, st))) return rc;
+      if ((rc = launch_rom_grad_contract_small(d, Sc, ga, st, ga.defer_sum ? h->back : nullptr))) return rc;
       continue;
     }
     if (h->projection == FINROM_PROJECTION_DIRECT && rom_splitk_applies(d, Sc) && d.n_obs <= 64 && getenv("FINROM_OLD_SUBST") == nullptr) {
@@ -1465,7 +1466,7 @@ int finrom_mlp_create(const finrom_mlp_desc* a, finrom_mlp_t* out) {
 void finrom_mlp_destroy(finrom_mlp_t h) {
   if (!h) return;
   for (void* p : h->owned) (void)hipFree(p);
-  h->tape.release(); h->theta.release(); h->gth.release(); h->shift.release(); h->qtmp.release(); h->etmp.release();
+  h->tape.release(); h->theta.release(); h->gth.release(); h->shift.release(); h->qtmp.release(); h->etmp.release(); h->g0.release();
   delete h;
 }
 int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, void* stream) {
@@ -1511,18 +1512,24 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
     if ((rc = launch_subfin_avg(Sop, P, m.n_in, k, S, (double*)mlp->theta.p, st))) return rc;
     if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st))) return rc;
   }
-  rom->defer_gsum = one; rom->last_gpart = nullptr; rom->fuse = fm.on ? &fm : nullptr;
+  MlpBackFuse bf;
+  if (fm.on) {
+    if ((rc = mlp->g0.reserve((size_t)S * 64 * sizeof(float)))) return rc;
+    bf.on = 1; bf.m = m; bf.tape = (const float*)mlp->tape.p; bf.data = data; bf.data_stride = stride; bf.qoi_r = qoi_r; bf.e_nn = e_nn;
+    bf.g0_out = (float*)mlp->g0.p;
+  }
+  rom->defer_gsum = one; rom->last_gpart = nullptr; rom->fuse = fm.on ? &fm : nullptr; rom->back = bf.on ? &bf : nullptr;
   rc = finrom_rom_grad(rom, (const double*)mlp->theta.p, (const double*)mlp->shift.p, 1, S, loss, (double*)mlp->gth.p, nullptr,
                        qoi_r, info, st);
   const double* gparts = rom->last_gpart;
-  rom->defer_gsum = false; rom->last_gpart = nullptr; rom->fuse = nullptr;
+  rom->defer_gsum = false; rom->last_gpart = nullptr; rom->fuse = nullptr; rom->back = nullptr;
   if (rc) return rc;
   if (fm.on && gparts == nullptr) {                    // (the predicate above and finrom_rom_grad's own must agree)
     set_error("romml_grad: internal: the one-sample form was announced but not taken");
     return FINROM_ERR_UNSUPPORTED;
   }
   return launch_mlp_backward(m, S, (const float*)mlp->tape.p, data, stride, qoi_r, e_nn, (const double*)mlp->gth.p, Sop, P, grad, st,
-                             gparts, gparts ? ROM_GRAD_SMALL_NG : 0);
+                             gparts, gparts ? ROM_GRAD_SMALL_NG : 0, bf.on && gparts ? (const float*)mlp->g0.p : nullptr);
 }
 
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {

@@ -208,7 +208,14 @@ int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double
 // (g_parts, n_parts: instead of g_theta, its n_parts partial sums [S x n_parts x 32] as rom_grad_contract_small_kernel leaves them)
 int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
                         const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st,
-                        const double* g_parts = nullptr, int n_parts = 0);
+                        const double* g_parts = nullptr, int n_parts = 0, const float* g0_in = nullptr);
+// (g0_in [S x 64]: the walk back through the head and the hidden layers has been done -- MlpBackFuse -- and left its result there)
+struct MlpBackFuse {             // that walk as one more workgroup per sample of rom_grad_contract_small_kernel
+  int on = 0;
+  MlpDev m{};
+  const float* tape = nullptr; const double* data = nullptr; int64_t data_stride = 0;
+  const double* qoi_r = nullptr; const double* e_nn = nullptr; float* g0_out = nullptr;
+};
 
 // ---- ROM ------------------------------------------------------------------------------
 constexpr int ROM_MAX_PHASES = 8;
@@ -280,7 +287,7 @@ size_t rom_onesample_scratch_bytes(const RomDev& p, int64_t S);
 int launch_rom_onesample(const RomDev& p, const double* theta, int64_t S, double* part, int grad, const RomGradArgs& ga, double* w_r,
                          double* qoi_r, int* info, hipStream_t st, const MlpFuse* fuse = nullptr);
 constexpr int ROM_GRAD_SMALL_NG = 36;      // blocks per sample in rom_grad_contract_small_kernel
-int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st);
+int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st, const MlpBackFuse* bf = nullptr);
 int launch_rom_proj_splitk(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                            hipStream_t st, double* w_r, double* qoi_r, const RomGradArgs& ga);
 int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,

@@ -136,4 +136,48 @@ __device__ __forceinline__ void mlp_forward_body(const MlpDev& m, const double* 
   }
 }
 
+// Backward pass through the head and the hidden layers by ONE wave (tid < 64 of the caller): on return g[0 .. n_w) in LDS holds
+// g0 = d(1/2 |r|^2) / d(y0) without the final minus sign, r = data - (qoi_r + e_NN).  up: 64 floats of LDS scratch.
+// (mlp_backward_kernel runs it in its wave 0; in finrom_romml_grad's one-sample form it rides as one more workgroup of the ROM's
+// gradient contraction kernel -- it needs the residual, not the contraction -- and the backward kernel starts from its result.)
+__device__ __forceinline__ void mlp_backward_hidden_wave(const MlpDev& m, int64_t s, const float* __restrict__ tape,
+                                                         const double* __restrict__ data, int64_t data_stride,
+                                                         const double* __restrict__ qoi_r, const double* __restrict__ e_nn,
+                                                         float* __restrict__ g, float* __restrict__ up, int tid) {
+  const int nw = m.n_w;
+  const float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
+  if (tid < m.n_out) {
+    const double r = data[(data_stride ? s * data_stride : 0) + tid] - (qoi_r[s * m.n_out + tid] + e_nn[s * m.n_out + tid]);
+    up[tid] = (float)r;                                // dLoss/d(output) handed to vjp is +r; the minus sign comes at the end
+  }
+  wave_sync();
+  if (tid < nw) {                                      // through the head: no skip connection
+    float acc = 0.f;
+    for (int o = 0; o < m.n_out; ++o) acc = fmaf(up[o], m.Wh[tid * m.n_out + o], acc);
+    const float z = tp[m.n_layers * nw + tid];
+    g[tid] = acc * elu_grad_f(z) * m.scale[m.n_layers * nw + tid];
+  }
+  wave_sync();
+  for (int l = m.n_layers - 1; l >= 0; --l) {          // g <- g + (W_l g) * elu'(z_l) * s_l   (skip + branch)
+    const float* W = m.W + (int64_t)l * nw * nw;
+    float gnew = 0.f;
+    if (tid < nw) {
+      float acc = 0.f;
+      int j = 0;
+      for (; j + 16 <= nw; j += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = W[tid * nw + j + u];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = fmaf(g[j + u], wv[u], acc);
+      }
+      for (; j < nw; ++j) acc = fmaf(g[j], W[tid * nw + j], acc);
+      gnew = g[tid] + acc * elu_grad_f(tp[l * nw + tid]) * m.scale[l * nw + tid];
+    }
+    wave_sync();                                       // everybody has read the old g
+    if (tid < nw) g[tid] = gnew;
+    wave_sync();
+  }
+}
+
 }  // namespace finrom

@@ -39,16 +39,11 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
                                                            const double* __restrict__ qoi_r, const double* __restrict__ e_nn,
                                                            const double* __restrict__ g_theta, const double* __restrict__ Sop,
                                                            int P, double* __restrict__ grad, const double* __restrict__ g_parts,
-                                                           int n_parts) {
+                                                           int n_parts, const float* __restrict__ g0_in) {
   __shared__ float g[MLP_MAX_W], up[MLP_MAX_W];
   __shared__ double gth[32];
   const int64_t s = blockIdx.x;
   const int tid = threadIdx.x, nw = m.n_w;
-  const float* tp = tape + s * (int64_t)(m.n_layers + 1) * nw;
-  if (tid < m.n_out) {
-    const double r = data[(data_stride ? s * data_stride : 0) + tid] - (qoi_r[s * m.n_out + tid] + e_nn[s * m.n_out + tid]);
-    up[tid] = (float)r;                                // dLoss/d(output) handed to vjp is +r; the minus sign comes at the end
-  }
   if (tid < P) {
     double t = 0.0;
     if (g_parts != nullptr) {                          // the contraction's partial sums, in its own fixed order (requested twelve at a time)
@@ -62,34 +57,11 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
     } else if (g_theta != nullptr) t = g_theta[s * P + tid];
     gth[tid] = t;
   }
-  __syncthreads();
   if (tid < 64) {                                      // head and hidden layers are 50 threads' work: wave 0 walks back alone, its
-    if (tid < nw) {                                    // hand-overs are its own program order (not barriers of sixteen waves)
-      float acc = 0.f;                                 // through the head: no skip connection
-      for (int o = 0; o < m.n_out; ++o) acc = fmaf(up[o], m.Wh[tid * m.n_out + o], acc);
-      const float z = tp[m.n_layers * nw + tid];
-      g[tid] = acc * elu_grad_f(z) * m.scale[m.n_layers * nw + tid];
-    }
-    wave_sync();
-    for (int l = m.n_layers - 1; l >= 0; --l) {        // g <- g + (W_l g) * elu'(z_l) * s_l   (skip + branch)
-      const float* W = m.W + (int64_t)l * nw * nw;
-      float gnew = 0.f;
-      if (tid < nw) {
-        float acc = 0.f;
-        int j = 0;
-        for (; j + 16 <= nw; j += 16) {
-          float wv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) wv[u] = W[tid * nw + j + u];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc = fmaf(g[j + u], wv[u], acc);
-        }
-        for (; j < nw; ++j) acc = fmaf(g[j], W[tid * nw + j], acc);
-        gnew = g[tid] + acc * elu_grad_f(tp[l * nw + tid]) * m.scale[l * nw + tid];
-      }
-      wave_sync();                                     // everybody has read the old g
-      if (tid < nw) g[tid] = gnew;
-      wave_sync();
+    if (g0_in != nullptr) {                            // hand-overs are its own program order (not barriers of sixteen waves) --
+      if (tid < nw) g[tid] = g0_in[s * MLP_MAX_W + tid];      // or somebody did it already (finrom_romml_grad's one-sample form)
+    } else {
+      mlp_backward_hidden_wave(m, s, tape, data, data_stride, qoi_r, e_nn, g, up, tid);
     }
   }
   __syncthreads();                                     // g is final: the other waves join for the first layer's transpose
@@ -130,15 +102,15 @@ int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double
 
 int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
                         const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st,
-                        const double* g_parts, int n_parts) {
+                        const double* g_parts, int n_parts, const float* g0_in) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_MISC, st);
   if (S <= MLP_SPLIT_MAX_S)
     hipLaunchKernelGGL(mlp_backward_kernel<MLP_SPLIT>, dim3((unsigned)S, MLP_SPLIT), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride,
-                       qoi_r, e_nn, g_theta, Sop, P, grad, g_parts, n_parts);
+                       qoi_r, e_nn, g_theta, Sop, P, grad, g_parts, n_parts, g0_in);
   else
     hipLaunchKernelGGL(mlp_backward_kernel<1>, dim3((unsigned)S), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride, qoi_r, e_nn,
-                       g_theta, Sop, P, grad, g_parts, n_parts);
+                       g_theta, Sop, P, grad, g_parts, n_parts, g0_in);
   FR_HIP(hipGetLastError());
   return 0;
 }

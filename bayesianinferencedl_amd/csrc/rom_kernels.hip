@@ -16,6 +16,7 @@
 
 #include <cstdlib>
 #include "rom_proj_device.h"
+#include "mlp_device.h"
 
 namespace finrom {
 
@@ -766,12 +767,20 @@ __global__ __launch_bounds__(64) void rom_grad_contract_kernel(RomDev p, int64_t
 // The same contraction for a handful of samples (one-sample call patterns): latency, not throughput -- ROM_GRAD_SMALL_NG
 // workgroups per sample, each walks its share of the blocks G_pi as flat arrays (64 consecutive entries per step, 16 steps in
 // flight) with v_r, w_r in LDS; the last workgroup to arrive (ticket) adds the partial sums in a fixed order.
-__global__ __launch_bounds__(256) void rom_grad_contract_small_kernel(RomDev p, int64_t S, RomGradArgs ga) {
+__global__ __launch_bounds__(256) void rom_grad_contract_small_kernel(RomDev p, int64_t S, RomGradArgs ga, MlpBackFuse bf) {
   extern __shared__ __attribute__((aligned(16))) double cs[];
   __shared__ double wsum[4];
   __shared__ double gacc[32];
-  const int r = p.r, R = p.rp, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = blockIdx.y, NG = gridDim.y;
+  const int r = p.r, R = p.rp, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, grp = blockIdx.y, NG = gridDim.y - (bf.on ? 1 : 0);
   const int64_t s = blockIdx.x;
+  if (bf.on && grp == NG) {                              // the spare workgroup: the error model's walk back to its first layer (wave 0)
+    __shared__ float bg[64], bup[64];
+    if (tid < 64) {
+      mlp_backward_hidden_wave(bf.m, s, bf.tape, bf.data, bf.data_stride, bf.qoi_r, bf.e_nn, bg, bup, tid);
+      if (tid < bf.m.n_w) bf.g0_out[s * 64 + tid] = bg[tid];
+    }
+    return;
+  }
   double* vs = cs; double* ws = cs + R;
   for (int t = tid; t < 2 * R; t += 256) cs[t] = ga.vw[s * (int64_t)(2 * R) + t];
   if (tid < 32) gacc[tid] = 0.0;
@@ -822,10 +831,13 @@ __global__ __launch_bounds__(256) void rom_grad_contract_small_kernel(RomDev p, 
   if (tid == 0) ga.ticket[s] = 0;                        // ready for the next call
 }
 
-int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st) {
+int launch_rom_grad_contract_small(const RomDev& p, int64_t S, const RomGradArgs& ga, hipStream_t st, const MlpBackFuse* bf) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  hipLaunchKernelGGL(rom_grad_contract_small_kernel, dim3((unsigned)S, ROM_GRAD_SMALL_NG), dim3(256), (size_t)2 * p.rp * sizeof(double), st, p, S, ga);
+  MlpBackFuse b{};
+  if (bf != nullptr && bf->on && ga.defer_sum) b = *bf;      // (only where the backward kernel follows in the same stream)
+  hipLaunchKernelGGL(rom_grad_contract_small_kernel, dim3((unsigned)S, ROM_GRAD_SMALL_NG + (b.on ? 1 : 0)), dim3(256),
+                     (size_t)2 * p.rp * sizeof(double), st, p, S, ga, b);
   FR_HIP(hipGetLastError());
   return 0;
 }
