@@ -136,17 +136,17 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
     out = {}
 
     def evaluate():
-        """dUq, out <- value and gradient at Kq (all static tensors: the same buffers at every call once captured)."""
+        """dUq (= grad U / c_pri), out <- value and gradient at Kq (all static tensors: the same buffers at every call once captured)."""
         res = solver_r.grad_romml_batch(Kq, data=data_t)
         torch.sub(Kq, mean_t, out=D)
-        torch.add(res["grad"] * c_lik, D, alpha=c_pri, out=dUq)
+        torch.add(D, res["grad"], alpha=c_lik / c_pri, out=dUq)     # dU / c_pri (one kernel; c_pri rides in the momentum updates' alpha)
         dUq.masked_fill_(res["info"].ne(0)[:, None], 0.0)           # an indefinite reduced operator: no force, rejected below
         out["loss"], out["grad"], out["info"] = res["loss"], res["grad"], res["info"]
 
     def step():
         Kq.add_(Pq, alpha=eps)
         evaluate()
-        Pq.add_(dUq, alpha=-eps)                                   # two half steps; the ends of a trajectory correct by +- eps/2
+        Pq.add_(dUq, alpha=-eps * c_pri)                           # two half steps; the ends of a trajectory correct by +- eps/2
 
     def potential_now():
         Uv = out["loss"] * c_lik + 0.5 * c_pri * (D * D).sum(1)
@@ -166,12 +166,12 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
         torch.index_select(lu_dev, 0, jt, out=lu)
         H0 = U + 0.5 * (P0[0] * P0[0]).sum(1)
         Kq.copy_(K); dUq.copy_(dU)
-        torch.add(P0[0], dUq, alpha=-0.5 * eps, out=Pq)             # first half step
+        torch.add(P0[0], dUq, alpha=-0.5 * eps * c_pri, out=Pq)     # first half step
         for _ in range(n_leapfrog):                                 # each step's input depends on the previous gradient
             step()
             if hook is not None:
                 hook()
-        Pq.add_(dUq, alpha=0.5 * eps)                               # the last update was a whole step: back to a half
+        Pq.add_(dUq, alpha=0.5 * eps * c_pri)                       # the last update was a whole step: back to a half
         Uq = potential_now()
         H1 = Uq + 0.5 * (Pq * Pq).sum(1)
         ok = torch.isfinite(H1) & (lu[0] < H0 - H1)                 # (inf - inf = nan compares false, as on the host)
