@@ -684,6 +684,7 @@ int finrom_fom_set_band(finrom_fom_t h, const finrom_fom_band_desc* a) {
   if (rc) return rc;
   b.on = getenv("FINROM_BAND_TIMING") != nullptr ? 2 : 1;      // 2: block 0 reports its phase clocks in sample 0's QoI (diagnostic)
   if (getenv("FINROM_BAND_NOMEM") != nullptr) b.on |= 4;       // timing experiment (m <= 12 kernel): no L / y / w traffic, garbage results
+  if (getenv("FINROM_BAND_PRIO") != nullptr) b.on |= 8 * (atoi(getenv("FINROM_BAND_PRIO")) & 3);      // experiment: s_setprio 1..3 for the sweep's waves (bits 3-4)
   h->band = b;
   return 0;
 }

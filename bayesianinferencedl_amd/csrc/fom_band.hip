@@ -724,6 +724,9 @@ __global__ __launch_bounds__(64) void fom_band_kernel(BandDev p, const int* __re
   double* __restrict__ Gs = Gw + blk * (int64_t)p.gsize * 64;
   // (FINROM_BAND_NOMEM, timing experiment, results are garbage: the buffer ends behind the value slots, so the stores of L, y, w
   // are dropped and their loads return 0 by the hardware's range check -- the sweep's instructions without its HBM stream)
+  // (FINROM_BAND_PRIO, experiment: the sweep's waves ahead of the projection's at the issue arbiter -- they hold a register slot the
+  // projection wants back, so the sooner they finish the better?)
+  if ((p.on >> 3) & 3) { const int pr = (p.on >> 3) & 3; if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
   Io io{__builtin_amdgcn_make_buffer_rsrc(Gs, 0, ((p.on & 4) ? p.offL : p.gsize) * 512, 0x00020000), lane * 8};
   double* xs = xlds + lane;
   const PostTables T{act, lx_ptr, ent_extra, ecp_ptr, ecp_slot, ecp_off};
