@@ -291,73 +291,18 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
       });
     }
     // (a) the diagonal tile: 16 elimination steps on [T_kk | I]; M^T is carried (column operations), which is M as an A operand
-    // (This is what the sweep spends its time on: ~450 cycles per pivot, 96 pivots.  Not a latency chain -- taking the pivots off
-    // the vector update (p_{k+1} = D[k+1][k+1] - D[k+1][k]^2 / p_k from three v_readlanes, reciprocal instead of 1/sqrt on the
-    // chain) made it 6 % SLOWER -- but issue: one wave alone on its SIMD issues an instruction every >= 4 cycles and a step is
-    // ~100 of them, twelve ds_bpermutes among them.  Fewer instructions per pivot would need a 4 x 4-blocked tile
-    // factorisation with the rank-4 updates and the inverse on the matrix cores; not built.)
+    // (The 16 shuffle steps this used to be -- kept behind FINROM_DIAG_SHUFFLE -- were what the sweep spent its time on: ~450 cycles per
+    // pivot, 96 pivots.  Not a latency chain -- taking the pivots off the vector update (p_{k+1} = D[k+1][k+1] - D[k+1][k]^2 / p_k
+    // from three v_readlanes, reciprocal instead of 1/sqrt on the chain) made it 6 % SLOWER -- but issue: one wave alone on its
+    // SIMD issues an instruction every >= 4 cycles and a step was ~100 of them, twelve ds_bpermutes among them.)
     double Am[4];
 #ifdef FINROM_SOLVE_CLOCKS
     const long long cd0 = wall_clock64();
 #endif
 #ifndef FINROM_DIAG_SHUFFLE
     {
-      // 4 x 4-blocked: in C/D layout block row b of the tile IS register b.  Per block: the 4 x 4 diagonal block S is read out
-      // (ten v_readlanes), factored S = R^T R and inverted (Ib = R^-1) in wave-uniform arithmetic -- four 1/sqrt chains, no
-      // cross-lane traffic -- and Ib is placed as an MFMA A operand (AI: lane (q, c < 4) = Ib[q][c]).  Then everything else
-      // is the matrix cores': the block row of U (Ib^T D[b]: one MFMA), the rank-4 trailing update of the whole tile (ONE
-      // MFMA, A = B = that row), and block row b of M = U^-T = L^-1 by block forward substitution (b + 1 MFMAs; the operand
-      // U[j, b]^T is register j shifted along its rows: DPP row_shl, no LDS).  ~135 instructions per block against 4 x ~75.
-      v4d& D = T[0];
-      v4d Mc = (v4d){0.0, 0.0, 0.0, 0.0};               // M, C/D layout: Mc[g] at lane (q, c) = M[4 g + q][c]
-      double Ug[4];                                     // U, C/D layout
-      const v4d zero4 = (v4d){0.0, 0.0, 0.0, 0.0};
-      sfor<0, 4>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        const double s00 = read_lane_f64(D[b], 0 * 16 + 4 * b + 0), s01 = read_lane_f64(D[b], 0 * 16 + 4 * b + 1),
-                     s02 = read_lane_f64(D[b], 0 * 16 + 4 * b + 2), s03 = read_lane_f64(D[b], 0 * 16 + 4 * b + 3),
-                     s11 = read_lane_f64(D[b], 1 * 16 + 4 * b + 1), s12 = read_lane_f64(D[b], 1 * 16 + 4 * b + 2),
-                     s13 = read_lane_f64(D[b], 1 * 16 + 4 * b + 3), s22 = read_lane_f64(D[b], 2 * 16 + 4 * b + 2),
-                     s23 = read_lane_f64(D[b], 2 * 16 + 4 * b + 3), s33 = read_lane_f64(D[b], 3 * 16 + 4 * b + 3);
-        auto rsqrt2 = [&](double p_) {
-          bad |= !(p_ > 0.0);
-          double ri = __builtin_amdgcn_rsq(p_);
-#pragma unroll
-          for (int it = 0; it < 2; ++it) ri = ri * fma(-0.5 * p_ * ri, ri, 1.5);
-          return ri;
-        };
-        const double i00 = rsqrt2(s00);
-        const double r01 = s01 * i00, r02 = s02 * i00, r03 = s03 * i00;
-        const double i11 = rsqrt2(fma(-r01, r01, s11));
-        const double r12 = fma(-r01, r02, s12) * i11, r13 = fma(-r01, r03, s13) * i11;
-        const double i22 = rsqrt2(fma(-r12, r12, fma(-r02, r02, s22)));
-        const double r23 = fma(-r12, r13, fma(-r02, r03, s23)) * i22;
-        const double i33 = rsqrt2(fma(-r23, r23, fma(-r13, r13, fma(-r03, r03, s33))));
-        const double i01 = -(r01 * i11) * i00, i12 = -(r12 * i22) * i11, i23 = -(r23 * i33) * i22;
-        const double i02 = -fma(r01, i12, r02 * i22) * i00, i13 = -fma(r12, i23, r13 * i33) * i11;
-        const double i03 = -fma(r01, i13, fma(r02, i23, r03 * i33)) * i00;
-        double AI = 0.0;                                 // lane (q, c): Ib[q][c] for c < 4, q <= c
-        AI = lane == 0 * 16 + 0 ? i00 : AI; AI = lane == 0 * 16 + 1 ? i01 : AI; AI = lane == 0 * 16 + 2 ? i02 : AI;
-        AI = lane == 0 * 16 + 3 ? i03 : AI; AI = lane == 1 * 16 + 1 ? i11 : AI; AI = lane == 1 * 16 + 2 ? i12 : AI;
-        AI = lane == 1 * 16 + 3 ? i13 : AI; AI = lane == 2 * 16 + 2 ? i22 : AI; AI = lane == 2 * 16 + 3 ? i23 : AI;
-        AI = lane == 3 * 16 + 3 ? i33 : AI;
-        // block row b of U = Ib^T D[b, :] (columns left of the block are not part of U)
-        const v4d ur = mma(AI, D[b], zero4);
-        const double Ub = c >= 4 * b ? ur[0] : 0.0;
-        Ug[b] = Ub;
-        if constexpr (b < 3) D = mma(c >= 4 * (b + 1) ? -Ub : 0.0, Ub, D);      // rows and columns behind the block: -= U[b, i]^T U[b, j]
-        // block row b of M: R^-T (I[b, :] - sum_{j < b} U[j, b]^T M[j, :])
-        v4d tm = (v4d){c == 4 * b + q ? 1.0 : 0.0, 0.0, 0.0, 0.0};
-        sfor<0, b>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          const unsigned long long ub = __builtin_bit_cast(unsigned long long, Ug[j]);
-          const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)ub, 0x100 + 4 * b, 0xf, 0xf, true);
-          const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(ub >> 32), 0x100 + 4 * b, 0xf, 0xf, true);
-          const double sh = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);      // lane (q, c) <- U[4 j + q][4 b + c]
-          tm = mma(c < 4 ? -sh : 0.0, Mc[j], tm);
-        });
-        Mc[b] = mma(AI, tm[0], zero4)[0];
-      });
+      // (4 x 4-blocked factorisation on the matrix cores: diag_tile_inverse, rom_proj_device.h)
+      const v4d Mc = diag_tile_inverse(T[0], q, c, lane, bad);
       // M_kb in its natural layout for the backward sweep, and back as the A operand of M T: Am[g] at lane (q, c) is M[c][q + 4 g]
 #pragma unroll
       for (int g = 0; g < 4; ++g) mbuf[kb * 256 + nat + 64 * g] = Mc[g];

@@ -470,6 +470,71 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
 }
 
 // ---------------------------------------------------------------------------------------
+// Factorisation of a 16 x 16 SPD diagonal tile D = U^T U and M = U^-T, 4 x 4-blocked, on the matrix cores (round 3; it replaces
+// 16 shuffle steps of ~75 instructions in the one-sample solve kernel and in fused_solve_mw).  D: C/D layout, destroyed.
+// Returns M in C/D layout (lane (q, c), register g: M[4 g + q][c]); bad |= 1 where a pivot is not positive.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ d4 diag_tile_inverse(d4& D, int q, int c, int lane, int& bad) {
+  auto mma_ = [](double a, double b, d4 cacc) -> d4 { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cacc, 0, 0, 0); };
+  // 4 x 4-blocked: in C/D layout block row b of the tile IS register b.  Per block: the 4 x 4 diagonal block S is read out
+  // (ten v_readlanes), factored S = R^T R and inverted (Ib = R^-1) in wave-uniform arithmetic -- four 1/sqrt chains, no
+  // cross-lane traffic -- and Ib is placed as an MFMA A operand (AI: lane (q, c < 4) = Ib[q][c]).  Then everything else
+  // is the matrix cores': the block row of U (Ib^T D[b]: one MFMA), the rank-4 trailing update of the whole tile (ONE
+  // MFMA, A = B = that row), and block row b of M = U^-T = L^-1 by block forward substitution (b + 1 MFMAs; the operand
+  // U[j, b]^T is register j shifted along its rows: DPP row_shl, no LDS).  ~135 instructions per block against 4 x ~75.
+  d4 Mc = (d4){0.0, 0.0, 0.0, 0.0};               // M, C/D layout: Mc[g] at lane (q, c) = M[4 g + q][c]
+  double Ug[4];                                     // U, C/D layout
+  const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+  sfor<0, 4>([&](auto bc) {
+    constexpr int b = decltype(bc)::value;
+    const double s00 = read_lane_f64(D[b], 0 * 16 + 4 * b + 0), s01 = read_lane_f64(D[b], 0 * 16 + 4 * b + 1),
+                 s02 = read_lane_f64(D[b], 0 * 16 + 4 * b + 2), s03 = read_lane_f64(D[b], 0 * 16 + 4 * b + 3),
+                 s11 = read_lane_f64(D[b], 1 * 16 + 4 * b + 1), s12 = read_lane_f64(D[b], 1 * 16 + 4 * b + 2),
+                 s13 = read_lane_f64(D[b], 1 * 16 + 4 * b + 3), s22 = read_lane_f64(D[b], 2 * 16 + 4 * b + 2),
+                 s23 = read_lane_f64(D[b], 2 * 16 + 4 * b + 3), s33 = read_lane_f64(D[b], 3 * 16 + 4 * b + 3);
+    auto rsqrt2 = [&](double p_) {
+      bad |= !(p_ > 0.0);
+      double ri = __builtin_amdgcn_rsq(p_);
+#pragma unroll
+      for (int it = 0; it < 2; ++it) ri = ri * fma(-0.5 * p_ * ri, ri, 1.5);
+      return ri;
+    };
+    const double i00 = rsqrt2(s00);
+    const double r01 = s01 * i00, r02 = s02 * i00, r03 = s03 * i00;
+    const double i11 = rsqrt2(fma(-r01, r01, s11));
+    const double r12 = fma(-r01, r02, s12) * i11, r13 = fma(-r01, r03, s13) * i11;
+    const double i22 = rsqrt2(fma(-r12, r12, fma(-r02, r02, s22)));
+    const double r23 = fma(-r12, r13, fma(-r02, r03, s23)) * i22;
+    const double i33 = rsqrt2(fma(-r23, r23, fma(-r13, r13, fma(-r03, r03, s33))));
+    const double i01 = -(r01 * i11) * i00, i12 = -(r12 * i22) * i11, i23 = -(r23 * i33) * i22;
+    const double i02 = -fma(r01, i12, r02 * i22) * i00, i13 = -fma(r12, i23, r13 * i33) * i11;
+    const double i03 = -fma(r01, i13, fma(r02, i23, r03 * i33)) * i00;
+    double AI = 0.0;                                 // lane (q, c): Ib[q][c] for c < 4, q <= c
+    AI = lane == 0 * 16 + 0 ? i00 : AI; AI = lane == 0 * 16 + 1 ? i01 : AI; AI = lane == 0 * 16 + 2 ? i02 : AI;
+    AI = lane == 0 * 16 + 3 ? i03 : AI; AI = lane == 1 * 16 + 1 ? i11 : AI; AI = lane == 1 * 16 + 2 ? i12 : AI;
+    AI = lane == 1 * 16 + 3 ? i13 : AI; AI = lane == 2 * 16 + 2 ? i22 : AI; AI = lane == 2 * 16 + 3 ? i23 : AI;
+    AI = lane == 3 * 16 + 3 ? i33 : AI;
+    // block row b of U = Ib^T D[b, :] (columns left of the block are not part of U)
+    const d4 ur = mma_(AI, D[b], zero4);
+    const double Ub = c >= 4 * b ? ur[0] : 0.0;
+    Ug[b] = Ub;
+    if constexpr (b < 3) D = mma_(c >= 4 * (b + 1) ? -Ub : 0.0, Ub, D);      // rows and columns behind the block: -= U[b, i]^T U[b, j]
+    // block row b of M: R^-T (I[b, :] - sum_{j < b} U[j, b]^T M[j, :])
+    d4 tm = (d4){c == 4 * b + q ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+    sfor<0, b>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const unsigned long long ub = __builtin_bit_cast(unsigned long long, Ug[j]);
+      const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)ub, 0x100 + 4 * b, 0xf, 0xf, true);
+      const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(ub >> 32), 0x100 + 4 * b, 0xf, 0xf, true);
+      const double sh = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);      // lane (q, c) <- U[4 j + q][4 b + c]
+      tm = mma_(c < 4 ? -sh : 0.0, Mc[j], tm);
+    });
+    Mc[b] = mma_(AI, tm[0], zero4)[0];
+  });
+  return Mc;
+}
+
+// ---------------------------------------------------------------------------------------
 // Factorisation + reduced QoI for the multi-wave kernels WITHOUT leaving the registers (factor == 3: only qoi_r is wanted).
 // The block triangle of A_r stays where the main loop accumulated it -- tile idx in wave idx % NW -- and LDS only carries what
 // one block row hands to the others.  Right-looking by block rows kb:
@@ -532,34 +597,8 @@ __device__ __forceinline__ void fused_solve_mw(const RomDev& p, d4 (&acc)[(NB * 
     constexpr int kb = decltype(kc)::value;
     constexpr int dI = tidx<NB>(kb, kb);
     if constexpr (dI % NW == W) {                          // (a)
-      d4& D = acc[dI / NW];
-      double E[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) E[g] = (q + 4 * g == c) ? 1.0 : 0.0;
       int bad = 0;
-#pragma unroll
-      for (int gs = 0; gs < 4; ++gs)
-#pragma unroll 1
-        for (int qs = 0; qs < 4; ++qs) {
-          const int st = 4 * gs + qs;
-          const double piv = read_lane_f64(D[gs], qs * 16 + st);
-          bad |= !(piv > 0.0);
-          double rinv = __builtin_amdgcn_rsq(piv);
-#pragma unroll
-          for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
-          const double sc = (q == qs) ? rinv : 1.0;
-          D[gs] *= sc; E[gs] *= sc;
-          const double rvD = __shfl(D[gs], qs * 16 + c), rvE = __shfl(E[gs], qs * 16 + c);
-          // rows below the pivot only: registers g < gs hold rows < 4 gs <= st -- nothing to fetch or update there (gs is unrolled)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (g >= gs) {
-              const double v = __shfl(D[gs], qs * 16 + ((q + 4 * g) & 15));
-              const double m = (q + 4 * g > st) ? v : 0.0;                // U[st][row of this lane]
-              D[g] = fma(-m, rvD, D[g]); E[g] = fma(-m, rvE, E[g]);      // (the source lanes of the shuffles, row st, have m = 0)
-            }
-          }
-        }
+      const d4 E = diag_tile_inverse(acc[dI / NW], q, c, lane, bad);      // (4 x 4-blocked, on the matrix cores; 16 shuffle steps before)
 #pragma unroll
       for (int g = 0; g < 4; ++g) minvT[c * 16 + q + 4 * g] = E[g];        // E = M[row q + 4g][col c]
       if (bad && lane == 0) { atomicOr(flag, 1); if (info != nullptr) atomicOr(&info[s], 2); }
