@@ -148,9 +148,12 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
         evaluate()
         Pq.add_(dUq, alpha=-eps * c_pri)                           # two half steps; the ends of a trajectory correct by +- eps/2
 
+    inf = float("inf")
+
     def potential_now():
-        Uv = out["loss"] * c_lik + 0.5 * c_pri * (D * D).sum(1)
-        return torch.where(out["info"].ne(0) | ~torch.isfinite(Uv), torch.full_like(Uv, float("inf")), Uv)
+        # (as few kernels as possible: each is a node of the proposal's graph, ~1.6 us)
+        Uv = torch.add(torch.linalg.vecdot(D, D).mul_(0.5 * c_pri), out["loss"], alpha=c_lik)
+        return torch.nan_to_num_(Uv, nan=inf, posinf=inf, neginf=inf).masked_fill_(out["info"].ne(0), inf)
 
     recorded, evals = [], 0
 
@@ -164,7 +167,7 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
         """One proposal on the static tensors: momentum and log u of slice jt, trajectory, Metropolis test, state update."""
         torch.index_select(P_dev, 0, jt, out=P0)
         torch.index_select(lu_dev, 0, jt, out=lu)
-        H0 = U + 0.5 * (P0[0] * P0[0]).sum(1)
+        H0 = torch.add(U, torch.linalg.vecdot(P0[0], P0[0]), alpha=0.5)
         Kq.copy_(K); dUq.copy_(dU)
         torch.add(P0[0], dUq, alpha=-0.5 * eps * c_pri, out=Pq)     # first half step
         for _ in range(n_leapfrog):                                 # each step's input depends on the previous gradient
@@ -173,9 +176,9 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
                 hook()
         Pq.add_(dUq, alpha=0.5 * eps * c_pri)                       # the last update was a whole step: back to a half
         Uq = potential_now()
-        H1 = Uq + 0.5 * (Pq * Pq).sum(1)
-        ok = torch.isfinite(H1) & (lu[0] < H0 - H1)                 # (inf - inf = nan compares false, as on the host)
-        K.copy_(torch.where(ok[:, None], Kq, K)); U.copy_(torch.where(ok, Uq, U)); dU.copy_(torch.where(ok[:, None], dUq, dU))
+        H1 = torch.add(Uq, torch.linalg.vecdot(Pq, Pq), alpha=0.5)
+        ok = lu[0] < H0 - H1                                        # (H1 = inf or nan compares false, as on the host: rejected)
+        torch.where(ok[:, None], Kq, K, out=K); torch.where(ok, Uq, U, out=U); torch.where(ok[:, None], dUq, dU, out=dU)
         acc.add_(ok)
         jt.add_(1); pt.add_(1)
         if trace is not None:
