@@ -114,6 +114,7 @@ struct finrom_rom_s {
   bool defer_gsum = false; const double* last_gpart = nullptr;
   const MlpFuse* fuse = nullptr;       // (same path) the error model's forward pass as a workgroup of the contraction kernel
   const MlpBackFuse* back = nullptr;   // (same path) its walk back through the hidden layers as a workgroup of the gradient contraction
+  bool info_store = false;             // (same path) the solve kernel stores info instead of or-ing into it
 };
 struct finrom_sampler_s { double* U = nullptr; int n = 0; Scratch xi; };
 struct finrom_mlp_s { MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp, g0; };
@@ -1267,6 +1268,7 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
       }
       ga.vw = (double*)h->vw.p; ga.gpart = (double*)((char*)h->vw.p + vw_bytes); ga.ticket = (int*)h->grad_ticket.p;
       ga.defer_sum = h->defer_gsum && s0 == 0 && Sc == S;
+      ga.info_store = ga.defer_sum && h->info_store;
       h->last_gpart = ga.defer_sum ? ga.gpart : nullptr;
       if ((rc = launch_rom_onesample(d, theta + s0 * d.P, Sc, (double*)h->part.p, 1, ga, w_r ? w_r + s0 * d.r : nullptr, q,
                                      info ? info + s0 : nullptr, st, ga.defer_sum ? h->fuse : nullptr))) return rc;
@@ -1519,11 +1521,14 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
     bf.on = 1; bf.m = m; bf.tape = (const float*)mlp->tape.p; bf.data = data; bf.data_stride = stride; bf.qoi_r = qoi_r; bf.e_nn = e_nn;
     bf.g0_out = (float*)mlp->g0.p;
   }
+  // info is this call's alone: stored by the one-sample solve kernel, cleared here for the other forms (whose kernels or flags in)
+  if (info != nullptr && !one) FR_HIP(hipMemsetAsync(info, 0, (size_t)S * sizeof(int32_t), st));
   rom->defer_gsum = one; rom->last_gpart = nullptr; rom->fuse = fm.on ? &fm : nullptr; rom->back = bf.on ? &bf : nullptr;
+  rom->info_store = one;
   rc = finrom_rom_grad(rom, (const double*)mlp->theta.p, (const double*)mlp->shift.p, 1, S, loss, (double*)mlp->gth.p, nullptr,
                        qoi_r, info, st);
   const double* gparts = rom->last_gpart;
-  rom->defer_gsum = false; rom->last_gpart = nullptr; rom->fuse = nullptr; rom->back = nullptr;
+  rom->defer_gsum = false; rom->last_gpart = nullptr; rom->fuse = nullptr; rom->back = nullptr; rom->info_store = false;
   if (rc) return rc;
   if (fm.on && gparts == nullptr) {                    // (the predicate above and finrom_rom_grad's own must agree)
     set_error("romml_grad: internal: the one-sample form was announced but not taken");

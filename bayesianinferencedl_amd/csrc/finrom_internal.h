@@ -257,6 +257,7 @@ struct RomGradArgs {                      // adjoint-gradient stage of rom_solve
   int npairs = 0; const int* pair_p = nullptr; const int* pair_i = nullptr; const double* Gt = nullptr;
   double* gpart = nullptr; int* ticket = nullptr;   // small batches (rom_grad_contract_small_kernel): [S x NG x 32] partial sums, [S] arrival counters (zero between calls)
   int defer_sum = 0;        // (small batches) leave the NG partial sums in gpart: the consumer adds them (mlp_backward_kernel in finrom_romml_grad)
+  int info_store = 0;       // (one-sample solve kernel) info[s] is stored (0 or 2), not or-ed into: the caller did not have to clear it
   double* vw = nullptr;     // scratch [S x 2 rp]: when set, the substitution kernel leaves v_r and w_r there and the
                             // contraction g_i = sum_p theta_p v_r^T G_pi w_r runs in rom_grad_contract_kernel (fp64 MFMA, 16 samples per wave)
 };

@@ -383,7 +383,10 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
   part_q += __shfl_xor(part_q, 16);
   part_q += __shfl_xor(part_q, 32);                     // lane column c = o + 1: qoi_r[o]
   const double nanv = __builtin_nan("");
-  if (bad && info != nullptr && lane == 0) atomicOr(&info[s], 2);
+  if (info != nullptr && lane == 0) {
+    if (grad && ga.info_store) info[s] = bad ? 2 : 0;
+    else if (bad) atomicOr(&info[s], 2);
+  }
   if (qoi_r != nullptr && lane >= 1 && lane <= p.n_obs) qoi_r[s * p.n_obs + lane - 1] = bad ? nanv : part_q;
   if (grad) {
     const double* dat = ga.data + (ga.data_stride ? s * ga.data_stride : 0);

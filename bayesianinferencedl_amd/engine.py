@@ -578,7 +578,7 @@ def romml_grad(rom, mlp, Sop_buf, K, data):
     per_sample = 1 if data.ndim == 2 else 0
     db = _Batch(data, n_obs)
     grad, gp = b.new((S, n), zero=False); loss, lp = b.new((S,), zero=False); q, qp = b.new((S, n_obs), zero=False)
-    e, ep = b.new((S, n_obs), zero=False); info, ip = b.new((S,), "i4")
+    e, ep = b.new((S, n_obs), zero=False); info, ip = b.new((S,), "i4", zero=False)      # (finrom_romml_grad overwrites info)
     check(lib().finrom_romml_grad(rom._h, mlp._h, Sop_buf.ptr, b.ptr, db.ptr, per_sample, S, gp, lp, qp, ep, ip, b.stream),
           "finrom_romml_grad")
     _sync_if_mixed(b, db)

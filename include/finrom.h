@@ -339,7 +339,8 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
  * finrom_mlp_create copies the weights (host pointers, fp32, row-major as listed); n_w <= 64, n_out <= 64.
  * finrom_romml_grad: k [S x n] device, data [n_obs] (data_per_sample = 0) or [S x n_obs]; outputs grad [S x n], loss [S],
  * optional qoi_r / e_nn [S x n_obs] (NULL to skip); Sop [P x n] device (the sub-fin averaging operator = dsigma_dk);
- * finrom_rom_set_gradient must have been called on `rom`.  finrom_mlp_predict: e [S x n_out] only (:360). */
+ * finrom_rom_set_gradient must have been called on `rom`.  info [S] (optional) is OVERWRITTEN by finrom_romml_grad -- 0, or the
+ * flags of finrom_rom_solve -- so the caller need not clear it.  finrom_mlp_predict: e [S x n_out] only (:360). */
 typedef struct {
   int32_t n_in, n_w, n_layers, n_out;
   const float* W0; const float* b0;            /* [n_in x n_w], [n_w]                                  y0 = x W0 + b0 */

@@ -556,6 +556,36 @@ def test_grad_romml_parity(problems, spaces, tmp_path):
         assert abs(res["loss"][s] - lo) < 1e-5 * lo and np.linalg.norm(res["grad"][s] - go) < 1e-4 * np.linalg.norm(go)
 
 
+@pytest.mark.parametrize("S", [3, 100])
+def test_grad_romml_info_is_this_calls_alone(problems, spaces, S):
+    """finrom_romml_grad OVERWRITES info (include/finrom.h): the Python side hands it an uninitialised array.  A field with a NaN
+    makes the reduced operator's first pivot NaN -> flag 2 and NaN outputs for that sample only; the next call on clean fields
+    reports zeros everywhere -- on the one-sample form (S = 3: the solve kernel stores the flag) and on the batched form
+    (S = 100: cleared by the library, flags or-ed in)."""
+    import torch
+    from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    m = 4
+    prob = problems(m); V = spaces(m)
+    phi = oracle_basis(prob, 8)
+    model = ResBnFcModel(n_in=prob.n, n_out=9, n_layers=2, n_weights=12, seed=5)
+    rom = AffineROMFin(V, model, phi); rom.set_data(np.linspace(0.2, 1.0, 9))
+    rng = np.random.default_rng(3)
+    K = np.exp(0.3 * rng.standard_normal((S, prob.n)))
+    clean = rom.grad_romml_batch(torch.from_numpy(K).cuda())
+    assert (clean["info"].cpu().numpy() == 0).all() and np.isfinite(clean["grad"].cpu().numpy()).all()
+    Kb = K.copy(); Kb[1, 7] = np.nan
+    dirty = rom.grad_romml_batch(torch.from_numpy(Kb).cuda())
+    info = dirty["info"].cpu().numpy()
+    assert info[1] != 0 and (np.delete(info, 1) == 0).all(), info
+    g = dirty["grad"].cpu().numpy()
+    assert np.array_equal(np.delete(g, 1, axis=0), np.delete(clean["grad"].cpu().numpy(), 1, axis=0))
+    for _ in range(3):                                     # fresh, uninitialised info arrays (the allocator hands the old blocks back)
+        again = rom.grad_romml_batch(torch.from_numpy(K).cuda())
+        assert (again["info"].cpu().numpy() == 0).all()
+        assert np.array_equal(again["grad"].cpu().numpy(), clean["grad"].cpu().numpy())
+
+
 def test_unsupported_basis_size_is_an_error_not_a_crash(spaces):
     """r > 208 (13 blocks of 16) is outside the projection kernels' range: the ROM handle is created, the solve reports
     FINROM_ERR_UNSUPPORTED through the Python layer."""
