@@ -498,7 +498,7 @@ def run_hmc(args, rank, local_rank, world):
             cpu = hmc_cpu_baseline(args, phi, model, solver_r.data, K0, res)
         print(json.dumps({
             "metric": "ROM+DL value-and-gradient evaluations/sec (HMC chains, BASELINE configs[4])",
-            "value": total / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total / dt, "unit": "evals/s", "n_gpus": world, "steps": n_evals - 1, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / n_evals, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64 (ROM) + f32 (error model)", "data": "synthetic",
             "config": {"workload": f"HMC: {args.chains} chains x {n_evals} dependent one-sample grad_romml calls, lattice m={args.m} "
