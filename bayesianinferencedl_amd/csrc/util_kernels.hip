@@ -19,11 +19,25 @@ __global__ __launch_bounds__(256) void subfin_avg_kernel(const double* __restric
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) acc[p] = 0.0;
   const double* ks = k + s * n;
-  for (int j = lane; j < n; j += 64) {
-    const double kj = ks[j];
+  // (four passes of 64 columns requested together -- one value of k and P of S per pass -- and added in the order of the
+  // columns, as before: the first version waited for every pass on its own, 25 dependent trips to memory for a 1597-node field --
+  // 34 us for one sample, and 0.4 TB/s for a batch of them)
+  constexpr int UP = 4;
+  for (int j0 = lane; j0 < n; j0 += 64 * UP) {
+    double kv[UP], sv[MAXP][UP];
+#pragma unroll
+    for (int u = 0; u < UP; ++u) kv[u] = j0 + 64 * u < n ? ks[j0 + 64 * u] : 0.0;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p)
-      if (p < P) acc[p] = fma(Sop[(int64_t)p * n + j], kj, acc[p]);
+      if (p < P) {
+#pragma unroll
+        for (int u = 0; u < UP; ++u) sv[p][u] = j0 + 64 * u < n ? Sop[(int64_t)p * n + j0 + 64 * u] : 0.0;
+      }
+#pragma unroll
+    for (int u = 0; u < UP; ++u)
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p)
+        if (p < P && j0 + 64 * u < n) acc[p] = fma(sv[p][u], kv[u], acc[p]);
   }
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
