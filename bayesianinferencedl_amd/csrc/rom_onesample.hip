@@ -448,17 +448,23 @@ template <int NB>
 int launch_small(const RomDev& p, const double* theta, int64_t S, int NC, double* part, int grad, const RomGradArgs& ga, double* w_r,
                  double* qoi_r, int* info, hipStream_t st, const MlpFuse* fuse) {
   constexpr int lds_a = 3 * onesample_nt<NB>() * 256 * (int)sizeof(double), lds_b = small_solve_lds<NB>() * (int)sizeof(double);
+  // the spare workgroup keeps the network's input (n_in floats) in the same dynamic LDS: a small basis' three partial triangles
+  // can be smaller than that
+  constexpr int lds_cap = lds_a > 96 * 1024 ? lds_a : 96 * 1024;
   MlpFuse fm{};
-  if (fuse != nullptr && fuse->on && (size_t)fuse->m.n_in * sizeof(float) <= (size_t)lds_a) fm = *fuse;      // (its input in the same LDS)
-  else if (fuse != nullptr && fuse->on) { set_error("rom_onesample: error model input does not fit the contraction's LDS"); return FINROM_ERR_UNSUPPORTED; }
+  if (fuse != nullptr && fuse->on) {
+    if ((size_t)fuse->m.n_in * sizeof(float) > (size_t)lds_cap) { set_error("rom_onesample: error model input does not fit LDS"); return FINROM_ERR_UNSUPPORTED; }
+    fm = *fuse;
+  }
+  const int lds_launch = fm.on && fm.m.n_in * (int)sizeof(float) > lds_a ? (fm.m.n_in * (int)sizeof(float) + 15) / 16 * 16 : lds_a;
   static PerDeviceOnce once;
   if (int rc = once.run([&]() -> int {
-        FR_HIP(hipFuncSetAttribute((const void*)rom_small_proj_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a));
+        FR_HIP(hipFuncSetAttribute((const void*)rom_small_proj_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap));
         FR_HIP(hipFuncSetAttribute((const void*)rom_small_solve_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
         return 0; })) return rc;
   {
     ScopedKernelTimer t(K_ROM_PROJ, st);
-    hipLaunchKernelGGL(rom_small_proj_kernel<NB>, dim3((unsigned)S, (unsigned)(NC + (fm.on ? 1 : 0))), dim3(256), lds_a, st, p, theta, S, NC, part,
+    hipLaunchKernelGGL(rom_small_proj_kernel<NB>, dim3((unsigned)S, (unsigned)(NC + (fm.on ? 1 : 0))), dim3(256), lds_launch, st, p, theta, S, NC, part,
                        p.kmeta, fm);
     FR_HIP(hipGetLastError());
   }

@@ -556,6 +556,33 @@ def test_grad_romml_parity(problems, spaces, tmp_path):
         assert abs(res["loss"][s] - lo) < 1e-5 * lo and np.linalg.norm(res["grad"][s] - go) < 1e-4 * np.linalg.norm(go)
 
 
+@pytest.mark.parametrize("r", [8, 33, 81])
+def test_grad_romml_one_sample_form_at_survey_mesh(problems, spaces, r):
+    """The one-sample form of finrom_romml_grad on the survey's mesh (m = 12, n = 1597) for bases of 1, 3 and 6 tiles: the error
+    model's forward pass rides in the ROM's contraction kernel and keeps its input in that kernel's dynamic LDS -- at r <= 16 the
+    contraction's own three partial triangles (6 KB) are smaller than the input (6.4 KB).  Against the oracle, and a sample
+    alone = the same sample inside a batch of four."""
+    import torch
+    from bayesianinferencedl_amd.deep_learning.dl_model import ResBnFcModel
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    m = 12
+    prob = problems(m); V = spaces(m)
+    phi = oracle_basis(prob, r)
+    model = ResBnFcModel(n_in=prob.n, n_out=9, n_layers=2, n_weights=16, seed=7)
+    data = np.linspace(0.2, 1.0, 9)
+    rom = AffineROMFin(V, model, phi); rom.set_data(data)
+    ro = O.AffineROMOracle(prob, phi); ro.set_data(data)
+    K = np.exp(0.3 * np.random.default_rng(r).standard_normal((4, prob.n)))
+    res = rom.grad_romml_batch(torch.from_numpy(K).cuda())
+    assert (res["info"].cpu().numpy() == 0).all()
+    g, loss = res["grad"].cpu().numpy(), res["loss"].cpu().numpy()
+    for s_ in (0, 3):
+        go, lo = O.grad_romml_oracle(ro, model, K[s_])
+        assert abs(loss[s_] - lo) <= 2e-5 * abs(lo) and np.linalg.norm(g[s_] - go) <= 1e-4 * np.linalg.norm(go), (r, s_)
+    one = rom.grad_romml_batch(torch.from_numpy(K[2:3]).cuda())
+    assert np.array_equal(one["grad"].cpu().numpy()[0], g[2]) and one["loss"].cpu().numpy()[0] == loss[2]
+
+
 @pytest.mark.parametrize("S", [3, 100])
 def test_grad_romml_info_is_this_calls_alone(problems, spaces, S):
     """finrom_romml_grad OVERWRITES info (include/finrom.h): the Python side hands it an uninitialised array.  A field with a NaN
