@@ -86,6 +86,10 @@ SIGNATURES = {
     "finrom_set_device": (C.c_int, [C.c_int]),
     "finrom_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "finrom_free": (C.c_int, [C.c_void_p]),
+    "finrom_free_async": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "finrom_note_stream": (C.c_int, [C.c_void_p]),
+    "finrom_deferred_count": (C.c_int, []),
+    "finrom_flush_deferred": (C.c_int, []),
     "finrom_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "finrom_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "finrom_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
@@ -132,7 +136,7 @@ SIGNATURES = {
     "finrom_comm_destroy": (C.c_int, [C.c_void_p]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 # finrom_fom_last_path codes (include/finrom.h)
 FOM_PATHS = {0: "none", 1: "small_lds", 2: "small_global", 3: "interpreter", 4: "band_registers", 5: "band_lds_4wave",
              6: "band_lds_1wave", 7: "band_registers_qoi", 8: "band_lds_4wave_qoi"}
@@ -144,15 +148,32 @@ def lib_path() -> str:
     return os.environ.get("FINROM_LIB", _build.LIB)
 
 
+def _hip_runtime_loaded() -> bool:
+    """Is a HIP runtime (any libamdhip64) already mapped into this process -- torch's, /opt/rocm's under rocprofv3's preloaded
+    tool library, or another ROCm-linked module's?"""
+    try:
+        with open("/proc/self/maps") as f:
+            return any("libamdhip64" in line for line in f)
+    except OSError:
+        pass
+    try:                                                  # no /proc: ask the loader without loading anything (RTLD_NOLOAD = 4)
+        C.CDLL("libamdhip64.so.7", mode=4)
+        return True
+    except OSError:
+        return False
+
+
 def _share_torch_hip_runtime():
     """ONE HIP / HSA runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so.7 + libhsa-runtime64.so.1; this
     library is linked against /opt/rocm's.  With torch imported first the loader resolves our DT_NEEDED to torch's copy (same
     SONAME) and everything shares one runtime; with OUR library loaded first the process ends up with two HSA runtimes and the
     second one to initialise (torch) finds no GPU ("No HIP GPUs are available").  So: if torch is installed and not yet imported,
-    its two runtime libraries are loaded first, without importing torch.  FINROM_SYSTEM_HIP=1 keeps /opt/rocm's."""
+    its two runtime libraries are loaded first, without importing torch -- unless a HIP runtime is ALREADY mapped (rocprofv3's
+    preloaded tool library, another /opt/rocm-linked module): loading torch's copy by path on top of it would itself create the
+    two-runtime state.  FINROM_SYSTEM_HIP=1 keeps /opt/rocm's."""
     import importlib.util
     import sys
-    if "torch" in sys.modules or os.environ.get("FINROM_SYSTEM_HIP"):
+    if "torch" in sys.modules or os.environ.get("FINROM_SYSTEM_HIP") or _hip_runtime_loaded():
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -208,29 +229,43 @@ def f64(a):
     return a, a.ctypes.data_as(c_f64p)
 
 
-class DeviceBuffer:
-    """Device allocation owned by Python (finrom_malloc / finrom_free).  Small buffers (<= 16 MiB, the scalar call surface
-    and modest batches) are recycled through a per-process free list: hipMalloc / hipFree cost more than the kernels of
-    a one-sample call (the MAP / HMC call pattern, SURVEY configs[4])."""
+def note_current_stream():
+    """Tell the library about torch's current stream before anything is freed or destroyed: a finaliser may run inside somebody's
+    `torch.cuda.graph` capture (a generational GC pass between two captured calls), where hipFree would invalidate the capture or
+    wait on it.  The library queues the work while that stream captures (include/finrom.h, finrom_note_stream).  Returns the
+    stream handle (or None when torch has not initialised CUDA in this process)."""
+    import sys
+    t = sys.modules.get("torch")
+    if t is None or _lib is None:
+        return None
+    try:
+        if not t.cuda.is_initialized():
+            return None
+        st = t.cuda.current_stream().cuda_stream
+        _lib.finrom_note_stream(st)
+        return st
+    except Exception:                                     # interpreter shutdown: torch half torn down
+        return None
 
-    _POOL_MAX_EACH = 16 << 20
-    _POOL_MAX_TOTAL = 256 << 20
-    _pool = {}            # capacity -> [device pointers]
-    _pool_bytes = 0
+
+def destroy_handle(fn_name, handle):
+    """finrom_*_destroy from a close() / finaliser: capture-safe (see note_current_stream)."""
+    note_current_stream()
+    getattr(lib(), fn_name)(handle)
+
+
+class DeviceBuffer:
+    """Device allocation owned by Python (finrom_malloc / finrom_free).  Small buffers are recycled by the library's pool
+    (finrom_malloc: <= 16 MiB size classes; hipMalloc / hipFree cost more than the kernels of a one-sample call, the MAP / HMC call
+    pattern of SURVEY configs[4]).  `used_on(stream)`: a launch on a non-default stream consumed the buffer -- it is then handed back
+    with finrom_free_async, which parks it behind an event on that stream."""
 
     def __init__(self, nbytes: int):
         self.nbytes = int(nbytes)
-        cap = max(self.nbytes, 8)
-        if cap <= self._POOL_MAX_EACH:
-            cap = 1 << (cap - 1).bit_length()                 # size classes: powers of two
-            free = DeviceBuffer._pool.get(cap)
-            if free:
-                self.ptr, self._cap = free.pop(), cap
-                DeviceBuffer._pool_bytes -= cap
-                return
+        self._stream = None
         p = C.c_void_p()
-        check(lib().finrom_malloc(C.byref(p), cap), "finrom_malloc")
-        self.ptr, self._cap = p.value, cap
+        check(lib().finrom_malloc(C.byref(p), max(self.nbytes, 8)), "finrom_malloc")
+        self.ptr = p.value
 
     @classmethod
     def from_numpy(cls, a, stream=None):
@@ -248,16 +283,18 @@ class DeviceBuffer:
     def zero(self, stream=None):
         check(lib().finrom_memset(self.ptr, 0, self.nbytes, stream), "memset")
 
+    def used_on(self, stream):
+        if stream:
+            self._stream = stream
+
     def free(self):
         if getattr(self, "ptr", None):
-            cap = self._cap
-            if cap <= self._POOL_MAX_EACH and DeviceBuffer._pool_bytes + cap <= self._POOL_MAX_TOTAL:
-                # every user of this buffer was a library call that synchronised when results were copied back
-                DeviceBuffer._pool.setdefault(cap, []).append(self.ptr)
-                DeviceBuffer._pool_bytes += cap
+            ptr, self.ptr = self.ptr, None
+            note_current_stream()
+            if self._stream:
+                lib().finrom_free_async(ptr, self._stream)
             else:
-                lib().finrom_free(self.ptr)
-            self.ptr = None
+                lib().finrom_free(ptr)
 
     def __del__(self):
         try:

@@ -16,15 +16,88 @@ int hip_fail(hipError_t e, const char* what) {
   return FINROM_ERR_HIP;
 }
 
+// ---- stream capture registry, deferred frees (finrom_internal.h) ----------------------------------------------------------
+static std::mutex g_cap_mu;
+static std::vector<hipStream_t> g_cap_streams;          // streams last seen under capture
+struct DeferredCall { void (*fn)(void*); void* arg; };
+static std::vector<DeferredCall> g_deferred;            // capture-unsafe cleanups waiting for the capture to end
+static thread_local bool tl_call_captures = false;
+
+static bool query_capturing(hipStream_t st) {
+  if (st == nullptr) return false;                      // the legacy default stream cannot be captured (and must not be queried
+                                                        //  while another stream captures: that is itself an "implicit" violation)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const hipError_t e = hipStreamIsCapturing(st, &cs);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }      // a stream that no longer exists is not capturing
+  return cs != hipStreamCaptureStatusNone;              // (an invalidated capture is still open until EndCapture)
+}
+bool note_stream(hipStream_t st) {
+  const bool cap = query_capturing(st);
+  if (st == nullptr) return false;
+  std::lock_guard<std::mutex> lk(g_cap_mu);
+  auto it = std::find(g_cap_streams.begin(), g_cap_streams.end(), st);
+  if (cap && it == g_cap_streams.end()) g_cap_streams.push_back(st);
+  if (!cap && it != g_cap_streams.end()) g_cap_streams.erase(it);
+  return cap;
+}
+static bool any_capture_locked() {
+  for (size_t i = 0; i < g_cap_streams.size();) {
+    if (query_capturing(g_cap_streams[i])) ++i;
+    else g_cap_streams.erase(g_cap_streams.begin() + i);
+  }
+  return !g_cap_streams.empty();
+}
+bool any_capture() { std::lock_guard<std::mutex> lk(g_cap_mu); return any_capture_locked(); }
+bool call_captures() { return tl_call_captures; }
+static void hip_free_cb(void* p) { (void)hipFree(p); }
+void defer_or_run(void (*fn)(void*), void* arg) {
+  {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    if (any_capture_locked()) { g_deferred.push_back({fn, arg}); return; }
+  }
+  fn(arg);
+}
+void dev_free(void* p) { if (p) defer_or_run(hip_free_cb, p); }
+void flush_deferred() {
+  std::vector<DeferredCall> run;
+  {
+    std::lock_guard<std::mutex> lk(g_cap_mu);
+    if (g_deferred.empty() || any_capture_locked()) return;
+    run.swap(g_deferred);
+  }
+  for (auto& d : run) d.fn(d.arg);
+}
+int deferred_count() { std::lock_guard<std::mutex> lk(g_cap_mu); return (int)g_deferred.size(); }
+CallGuard::CallGuard(hipStream_t st) : prev(tl_call_captures) {
+  const bool cap = note_stream(st);
+  tl_call_captures = prev || cap;
+  if (!tl_call_captures) flush_deferred();
+}
+CallGuard::~CallGuard() { tl_call_captures = prev; }
+
 int Scratch::reserve(size_t bytes) {
-  if (bytes <= cap) return 0;
-  if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+  if (bytes <= cap) { captured = captured || tl_call_captures; return 0; }
+  if (tl_call_captures || any_capture()) {
+    set_error("a workspace of " + std::to_string(bytes) + " bytes is needed while a stream capture is open: run the same call once "
+              "(same handle, same batch size) before the capture begins");
+    return FINROM_ERR_UNSUPPORTED;
+  }
+  if (p) {
+    if (captured) retired.push_back(p);        // a graph captured earlier still points at it: keep it until the handle goes
+    else (void)hipFree(p);
+    p = nullptr; cap = 0; captured = false;
+  }
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) { p = nullptr; set_error("hipMalloc of " + std::to_string(bytes) + " scratch bytes failed"); return FINROM_ERR_NOMEM; }
   cap = bytes;
   return 0;
 }
-void Scratch::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+void Scratch::release() {
+  dev_free(p);
+  for (void* q : retired) dev_free(q);
+  retired.clear();
+  p = nullptr; cap = 0; captured = false;
+}
 
 // ---- profiling -------------------------------------------------------------------------
 static const char* kSlotNames[K_NUM] = {"pack", "fom_assemble", "fom_chol_solve", "unpack_w", "rom_proj_mfma",
@@ -103,6 +176,7 @@ struct finrom_rom_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int ensure_side() {
     if (side) return 0;
+    if (call_captures() || any_capture()) { set_error("the library's side stream cannot be created while a stream capture is open: run the call once before the capture"); return FINROM_ERR_UNSUPPORTED; }
     int lo = 0, hi = 0;
     FR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));          // numerically lower = higher priority
     FR_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, hi));
@@ -136,33 +210,131 @@ const char* finrom_last_error(void) { return g_err.c_str(); }
 
 int finrom_device_count(int* count) { if (!count) return FINROM_ERR_ARG; FR_HIP(hipGetDeviceCount(count)); return 0; }
 int finrom_set_device(int ordinal) { FR_HIP(hipSetDevice(ordinal)); return 0; }
+// finrom_malloc / finrom_free recycle small buffers (<= 16 MiB, size classes = powers of two, at most 256 MiB parked): the scalar
+// call surface allocates a handful of small buffers per call, and hipMalloc / hipFree cost more than its kernels.  A parked
+// buffer carries the event finrom_free_async recorded behind its last user; the next owner waits for it.
+namespace {
+constexpr size_t kPoolMaxEach = (size_t)16 << 20, kPoolMaxTotal = (size_t)256 << 20;
+struct Parked { void* p; hipEvent_t ev; };
+std::mutex g_pool_mu;
+std::vector<std::pair<void*, size_t>> g_pool_live;          // pooled allocations handed out: (pointer, size class)
+std::vector<std::pair<size_t, Parked>> g_pool_free;         // parked: (size class, buffer)
+size_t g_pool_free_bytes = 0;
+std::vector<hipEvent_t> g_pool_events;
+size_t size_class(size_t bytes) { size_t c = 256; while (c < bytes) c <<= 1; return c; }
+void event_destroy_cb(void* e) { (void)hipEventDestroy((hipEvent_t)e); }
+}  // namespace
+
 int finrom_malloc(void** dptr, size_t bytes) {
   if (!dptr) return FINROM_ERR_ARG;
   *dptr = nullptr;
   if (bytes == 0) return 0;
-  hipError_t e = hipMalloc(dptr, bytes);
-  if (e != hipSuccess) { set_error("hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorName(e)); return FINROM_ERR_NOMEM; }
+  const bool capture = any_capture();
+  if (!capture) flush_deferred();
+  size_t cap = bytes;
+  if (bytes <= kPoolMaxEach) {
+    cap = size_class(bytes);
+    std::unique_lock<std::mutex> lk(g_pool_mu);
+    for (size_t i = g_pool_free.size(); i-- > 0;) {          // (the most recently parked first)
+      if (g_pool_free[i].first != cap) continue;
+      Parked b = g_pool_free[i].second;
+      bool done = b.ev == nullptr;
+      if (!done) { done = hipEventQuery(b.ev) == hipSuccess; if (!done) (void)hipGetLastError(); }
+      if (!done && capture) continue;                          // (no host wait while a capture is open)
+      g_pool_free.erase(g_pool_free.begin() + i);
+      g_pool_free_bytes -= cap;
+      g_pool_live.emplace_back(b.p, cap);
+      lk.unlock();
+      if (b.ev != nullptr) {
+        // the last user (a launch on some non-blocking stream) must have finished before the new owner writes
+        const hipError_t e = done ? hipSuccess : hipEventSynchronize(b.ev);
+        std::lock_guard<std::mutex> lk2(g_pool_mu);
+        g_pool_events.push_back(b.ev);
+        if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize(pooled buffer)");
+      }
+      *dptr = b.p;
+      return 0;
+    }
+  }
+  if (capture) { set_error("finrom_malloc: refused while a stream capture is open (allocate before the capture begins)"); return FINROM_ERR_UNSUPPORTED; }
+  hipError_t e = hipMalloc(dptr, cap);
+  if (e != hipSuccess) { set_error("hipMalloc of " + std::to_string(cap) + " bytes failed: " + hipGetErrorName(e)); return FINROM_ERR_NOMEM; }
+  if (bytes <= kPoolMaxEach) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool_live.emplace_back(*dptr, cap); }
   return 0;
 }
-int finrom_free(void* dptr) { if (dptr) FR_HIP(hipFree(dptr)); return 0; }
+// stream: the stream of the buffer's last user, or NULL when that user is known to have finished / ran on the default stream
+static int pool_free(void* dptr, hipStream_t stream, bool have_stream) {
+  if (!dptr) return 0;
+  size_t cap = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_pool_live.size(); ++i)
+      if (g_pool_live[i].first == dptr) { cap = g_pool_live[i].second; g_pool_live.erase(g_pool_live.begin() + i); break; }
+  }
+  const bool st_captures = have_stream && note_stream(stream);
+  if (cap != 0 && !st_captures) {
+    hipEvent_t ev = nullptr;
+    if (have_stream && stream != nullptr) {
+      {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool_events.empty()) { ev = g_pool_events.back(); g_pool_events.pop_back(); }
+      }
+      if (ev == nullptr && !any_capture() && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+      if (ev != nullptr && hipEventRecord(ev, stream) != hipSuccess) { (void)hipGetLastError(); defer_or_run(event_destroy_cb, ev); ev = nullptr; cap = 0; }
+      if (ev == nullptr) cap = 0;                              // no event to be had: do not park, free (deferred under capture)
+    }
+    if (cap != 0) {
+      std::lock_guard<std::mutex> lk(g_pool_mu);
+      if (g_pool_free_bytes + cap <= kPoolMaxTotal) {
+        g_pool_free.push_back({cap, Parked{dptr, ev}});
+        g_pool_free_bytes += cap;
+        return 0;
+      }
+      if (ev != nullptr) g_pool_events.push_back(ev);
+    }
+  }
+  // not pooled, pool full, or last used inside a capture (the graph may replay it: never recycled, freed once no capture is open)
+  dev_free(dptr);
+  return 0;
+}
+int finrom_free(void* dptr) { return pool_free(dptr, nullptr, false); }
+int finrom_free_async(void* dptr, void* stream) { return pool_free(dptr, (hipStream_t)stream, true); }
+int finrom_note_stream(void* stream) {
+  const bool cap = note_stream((hipStream_t)stream);
+  if (!cap) flush_deferred();
+  return cap ? 1 : 0;
+}
+int finrom_deferred_count(void) { return deferred_count(); }
+int finrom_flush_deferred(void) { flush_deferred(); return deferred_count(); }
 int finrom_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
   if (bytes == 0) return 0;
+  CallGuard cg((hipStream_t)stream);
+  if (call_captures() || any_capture()) { set_error("finrom_memcpy_h2d synchronises: not while a stream capture is open"); return FINROM_ERR_UNSUPPORTED; }
   FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   FR_HIP(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 int finrom_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
   if (bytes == 0) return 0;
+  CallGuard cg((hipStream_t)stream);
+  if (call_captures() || any_capture()) { set_error("finrom_memcpy_d2h synchronises: not while a stream capture is open"); return FINROM_ERR_UNSUPPORTED; }
   FR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   FR_HIP(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
 int finrom_memset(void* dst, int value, size_t bytes, void* stream) {
   if (bytes == 0) return 0;
+  CallGuard cg((hipStream_t)stream);
+  if (stream == nullptr && any_capture()) { set_error("finrom_memset on the default stream: not while a stream capture is open"); return FINROM_ERR_UNSUPPORTED; }
   FR_HIP(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
   return 0;
 }
-int finrom_stream_sync(void* stream) { FR_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int finrom_stream_sync(void* stream) {
+  CallGuard cg((hipStream_t)stream);
+  if (call_captures()) { set_error("finrom_stream_sync on a capturing stream"); return FINROM_ERR_UNSUPPORTED; }
+  FR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
 
 int finrom_set_overlap(int on) { g_overlap = on != 0; return 0; }
 int finrom_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_on = on != 0; return 0; }
@@ -328,7 +500,7 @@ int finrom_fom_create(const finrom_fom_desc* a, finrom_fom_t* out) {
 
 void finrom_fom_destroy(finrom_fom_t h) {
   if (!h) return;
-  for (void* p : h->owned) (void)hipFree(p);
+  for (void* p : h->owned) dev_free(p);                 // (queued while a stream capture is open: finrom_internal.h)
   h->xT.release(); h->Gw.release(); h->gradT.release(); h->qtmp.release();
   delete h;
 }
@@ -406,6 +578,7 @@ static int fom_solve_stages(finrom_fom_t h, const double* x, int64_t S, double* 
 }
 
 int finrom_fom_solve(finrom_fom_t h, const double* x, int64_t S, double* qoi, double* w, int32_t* info, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || (S > 0 && (!x || (!qoi && h->d.n_obs > 0)))) { set_error("fom_solve: bad argument"); return FINROM_ERR_ARG; }
   return fom_solve_stages(h, x, S, qoi, w, info, (hipStream_t)stream, 3);
 }
@@ -723,6 +896,7 @@ int finrom_fom_set_band_gradient(finrom_fom_t h, const finrom_fom_band_grad_desc
 
 int finrom_fom_solve_rhs(finrom_fom_t h, const double* x, int64_t S, const double* rhs, int32_t nrhs, double* out, int32_t* info,
                          void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || nrhs < 0 || (S > 0 && nrhs > 0 && (!x || !rhs || !out))) { set_error("fom_solve_rhs: bad argument"); return FINROM_ERR_ARG; }
   if (!h->band.on) { set_error("fom_solve_rhs: needs the band sweep (finrom_fom_set_band)"); return FINROM_ERR_UNSUPPORTED; }
   if (S == 0 || nrhs == 0) return 0;
@@ -800,6 +974,7 @@ int finrom_fom_set_gradient(finrom_fom_t h, const finrom_fom_grad_desc* a) {
 
 int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int32_t data_per_sample, int64_t S,
                         double* grad, double* J, double* qoi, int32_t* info, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || (S > 0 && (!x || !data || !grad || !J))) { set_error("fom_gradient: bad argument"); return FINROM_ERR_ARG; }
   if (!h->d.has_grad && !h->band_grad.on) { set_error("fom_gradient: finrom_fom_set_gradient has not been called"); return FINROM_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
@@ -1100,12 +1275,12 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
 
 void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
-  for (void* p : h->owned) (void)hipFree(p);
+  for (void* p : h->owned) dev_free(p);
   h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release(); h->ticket.release(); h->grad_ticket.release();
   h->part.release();
-  if (h->side) (void)hipStreamDestroy(h->side);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side) defer_or_run([](void* s) { (void)hipStreamDestroy((hipStream_t)s); }, h->side);
+  if (h->ev_fork) defer_or_run([](void* e) { (void)hipEventDestroy((hipEvent_t)e); }, h->ev_fork);
+  if (h->ev_join) defer_or_run([](void* e) { (void)hipEventDestroy((hipEvent_t)e); }, h->ev_join);
   delete h;
 }
 
@@ -1174,6 +1349,7 @@ static int rom_project(finrom_rom_t h, const double* theta, int64_t S, int facto
 
 int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r, double* qoi_r, double* A_r,
                      double* B_r, int32_t* info, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || (S > 0 && (!theta || (!qoi_r && h->d.n_obs > 0)))) { set_error("rom_solve: bad argument"); return FINROM_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   const RomDev& d = h->d;
@@ -1237,6 +1413,7 @@ int finrom_rom_set_gradient(finrom_rom_t h, int32_t npairs, const int32_t* pair_
 
 int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int32_t data_per_sample, int64_t S,
                     double* J, double* g, double* w_r, double* qoi_r, int32_t* info, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || (S > 0 && (!theta || !data || !J || !g))) { set_error("rom_grad: bad argument"); return FINROM_ERR_ARG; }
   if (h->g_npairs == 0) { set_error("rom_grad: finrom_rom_set_gradient has not been called"); return FINROM_ERR_ARG; }
   const RomDev& d = h->d;
@@ -1318,6 +1495,7 @@ int finrom_rom_grad(finrom_rom_t h, const double* theta, const double* data, int
 
 // ---------------------------------------------------------------------------------------
 int finrom_subfin_avg(const double* Sop, int32_t P, int32_t n, const double* k, int64_t S, double* theta, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!Sop || P <= 0 || n <= 0 || S < 0 || (S > 0 && (!k || !theta))) { set_error("subfin_avg: bad argument"); return FINROM_ERR_ARG; }
   return launch_subfin_avg(Sop, P, n, k, S, theta, (hipStream_t)stream);
 }
@@ -1340,6 +1518,7 @@ static int trace_dump(const char* kind, long long* dbuf, size_t nwg) {
 int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, const double* x, int64_t S,
                        double* qoi, double* qoi_r, double* err, double* w, double* w_r, double* theta,
                        int32_t* info, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!fom || !rom || !Sop || S < 0 || (S > 0 && (!x || !qoi || !qoi_r))) { set_error("solve_pairs: bad argument"); return FINROM_ERR_ARG; }
   if (fom->d.n_obs != rom->d.n_obs) { set_error("solve_pairs: FOM and ROM observation operators differ in size"); return FINROM_ERR_ARG; }
   if (S == 0) return 0;
@@ -1419,14 +1598,16 @@ int finrom_sampler_create(const double* U, int32_t n, finrom_sampler_t* out) {
   *out = h;
   return 0;
 }
-void finrom_sampler_destroy(finrom_sampler_t h) { if (!h) return; if (h->U) (void)hipFree(h->U); h->xi.release(); delete h; }
+void finrom_sampler_destroy(finrom_sampler_t h) { if (!h) return; dev_free(h->U); h->xi.release(); delete h; }
 int finrom_sampler_draw(finrom_sampler_t h, const double* xi, int64_t S, double* k, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || (S > 0 && (!xi || !k))) { set_error("sampler_draw: bad argument"); return FINROM_ERR_ARG; }
   return launch_sampler(h->U, h->n, xi, S, k, (hipStream_t)stream);
 }
 
 int finrom_sampler_draw_seeded(finrom_sampler_t h, uint64_t seed, int64_t first_global_sample, int64_t S, double* k, double* xi_out,
                                void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || first_global_sample < 0 || (S > 0 && !k)) { set_error("sampler_draw_seeded: bad argument"); return FINROM_ERR_ARG; }
   hipStream_t st = (hipStream_t)stream;
   // pieces of <= 32k samples bound the xi scratch (1 GiB at n = 4101) when the caller does not want xi back
@@ -1468,11 +1649,12 @@ int finrom_mlp_create(const finrom_mlp_desc* a, finrom_mlp_t* out) {
 }
 void finrom_mlp_destroy(finrom_mlp_t h) {
   if (!h) return;
-  for (void* p : h->owned) (void)hipFree(p);
+  for (void* p : h->owned) dev_free(p);
   h->tape.release(); h->theta.release(); h->gth.release(); h->shift.release(); h->qtmp.release(); h->etmp.release(); h->g0.release();
   delete h;
 }
 int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!h || S < 0 || (S > 0 && (!k || !e))) { set_error("mlp_predict: bad argument"); return FINROM_ERR_ARG; }
   int rc = h->tape.reserve((size_t)S * (h->d.n_layers + 1) * h->d.n_w * sizeof(float));
   if (rc) return rc;
@@ -1481,6 +1663,7 @@ int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, vo
 int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
                       int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
                       int32_t* info, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (!rom || !mlp || !Sop || S < 0 || (S > 0 && (!k || !data || !grad || !loss))) { set_error("romml_grad: bad argument"); return FINROM_ERR_ARG; }
   const MlpDev& m = mlp->d;
   if (m.n_out != rom->d.n_obs) { set_error("romml_grad: the error model's outputs are not the ROM's observables"); return FINROM_ERR_ARG; }
@@ -1539,6 +1722,7 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
 }
 
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {
+  CallGuard cg((hipStream_t)stream);
   if (count < 0 || (count > 0 && (!a || !b || !out))) { set_error("sub: bad argument"); return FINROM_ERR_ARG; }
   return launch_sub(a, b, count, out, (hipStream_t)stream);
 }

@@ -45,10 +45,31 @@ struct ScopedKernelTimer {
   ~ScopedKernelTimer();
 };
 
+// ---- stream capture and device memory (finrom_api.hip) ---------------------------------------------------------------------
+// While a stream is being captured into a HIP graph (torch.cuda.graph: global capture mode) hipFree / hipMalloc / a synchronous
+// hipMemset from ANY thread are "unsafe" calls that invalidate the capture or wait on it.  The library therefore never issues
+// one while it knows of an open capture: frees and handle destructions are queued (dev_free, defer_or_run) and flushed by the
+// next call that finds no capture open; allocations and workspace growth fail with FINROM_ERR_UNSUPPORTED instead.
+// What it knows: every stream an entry point was handed (CallGuard) or was told about (finrom_note_stream) is queried with
+// hipStreamIsCapturing and remembered while it captures.
+bool note_stream(hipStream_t st);          // query st, update the registry; true = st is under capture
+bool any_capture();                        // re-queries the remembered streams
+bool call_captures();                      // the entry point on this thread's stack was handed a capturing stream
+void dev_free(void* p);                    // hipFree now, or queued while a capture is open
+void defer_or_run(void (*fn)(void*), void* arg);   // the same for any other capture-unsafe cleanup (stream / event destruction)
+void flush_deferred();                     // runs the queue if no capture is open
+int deferred_count();
+struct CallGuard {                         // first statement of every entry point that takes a stream
+  bool prev;
+  explicit CallGuard(hipStream_t st);
+  ~CallGuard();
+};
+
 template <class T>
 int upload(T** dptr, const T* host, size_t count) {
   *dptr = nullptr;
   if (count == 0) return 0;
+  if (any_capture()) { set_error("device tables cannot be created while a stream capture is open"); return FINROM_ERR_UNSUPPORTED; }
   hipError_t e = hipMalloc((void**)dptr, count * sizeof(T));
   if (e != hipSuccess) { set_error("hipMalloc failed (" + std::to_string(count * sizeof(T)) + " bytes)"); return FINROM_ERR_NOMEM; }
   FR_HIP(hipMemcpy(*dptr, host, count * sizeof(T), hipMemcpyHostToDevice));
@@ -70,9 +91,13 @@ struct PerDeviceOnce {
   }
 };
 
-// grow-only device scratch buffer owned by a handle
+// grow-only device scratch buffer owned by a handle.  A buffer that was used by a call under capture is referenced by that graph
+// for as long as the graph lives: when such a buffer has to grow later, the old allocation is retired (freed with the handle)
+// instead of freed; growth DURING a capture is refused (the same call, run once before the capture, sizes the workspace).
 struct Scratch {
   void* p = nullptr; size_t cap = 0;
+  bool captured = false;
+  std::vector<void*> retired;
   int reserve(size_t bytes);
   void release();
 };

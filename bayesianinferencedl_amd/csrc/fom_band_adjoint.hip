@@ -188,10 +188,12 @@ template <int NSF, int NSP, int NXM>
 int launch_adj(const BandDev& p, const BandGradDev& g, double* Gw, int64_t nblk, int64_t S, const double* qoi, const double* data,
                int64_t data_stride, double* gradT, double* J, hipStream_t st) {
   const size_t lds = (size_t)(p.n_obs + NXM) * 64 * sizeof(double);
+  // (the attribute is set once per device to the CAP, not to this handle's size: a later handle with more observation rows on the
+  //  same window sizes must not be refused its larger dynamic LDS; launch_fom_band_adjoint has checked lds <= the cap)
   static PerDeviceOnce once;
   if (lds > 64 * 1024)
     if (int rc = once.run([&]() -> int {
-          FR_HIP(hipFuncSetAttribute((const void*)fom_band_adjoint_kernel<NSF, NSP, NXM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          FR_HIP(hipFuncSetAttribute((const void*)fom_band_adjoint_kernel<NSF, NSP, NXM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
           return 0; })) return rc;
   hipLaunchKernelGGL((fom_band_adjoint_kernel<NSF, NSP, NXM>), dim3((unsigned)nblk), dim3(64), lds, st, p, p.act, p.lx_ptr, p.ent_extra,
                      p.iface_elim, g.bt_ptr, g.bt_obs, g.bt_w, g.g_ptr, g.g_a, g.g_b, g.g_w, Gw, S, qoi, data, data_stride, gradT, J);

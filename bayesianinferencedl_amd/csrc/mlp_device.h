@@ -33,7 +33,7 @@ __device__ __forceinline__ void mlp_forward_body(const MlpDev& m, const double* 
   constexpr int CH = NTHR >= 1024 ? 32 : 128;          // first-layer loads in flight per thread (fewer threads: deeper batches)
   __shared__ float part[MLP_PARTS][MLP_MAX_W];
   __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
-  __shared__ double tred[MLP_PARTS];
+  __shared__ double tred[MLP_PARTS > 16 ? MLP_PARTS : 16];      // (P <= 16: finrom_romml_grad)
   const int nw = m.n_w;
   for (int i = tid; i < m.n_in; i += MLP_THREADS) xs[i] = (float)k[s * m.n_in + i];
   if (theta_out != nullptr) {
@@ -41,13 +41,14 @@ __device__ __forceinline__ void mlp_forward_body(const MlpDev& m, const double* 
     // for five averages), a wave's slice dealt over its lanes in coalesced passes of 64, 13 passes requested at a time; ONE
     // value per wave to reduce across lanes.  (The first version had every thread carry all 16 partial sums through the input
     // loop and every wave reduce all of them: 16 x 6 shuffles of doubles per wave, 11.8 of the kernel's 25 us; now 4.6.)
-    const int wave = tid >> 6, lane = tid & 63, WPR = MLP_PARTS / P > 0 ? MLP_PARTS / P : 1, p = wave / WPR, part_ = wave - p * WPR;
-    double v = 0.0;
-    if (p < P) {
+    // (P > MLP_PARTS, e.g. nine averages on a 256-thread workgroup: one wave per row, the rows dealt over the waves in turns)
+    const int wave = tid >> 6, lane = tid & 63, WPR = MLP_PARTS / P > 0 ? MLP_PARTS / P : 1, NG = MLP_PARTS / WPR;
+    const int p0 = wave / WPR, part_ = wave - p0 * WPR;
+    for (int p = p0; p < P && p0 < NG; p += NG) {
       const int i0 = (int)((int64_t)m.n_in * part_ / WPR), i1 = (int)((int64_t)m.n_in * (part_ + 1) / WPR);
       const double* __restrict__ srow = Sop + (int64_t)p * m.n_in;
       const double* __restrict__ krow = k + s * m.n_in;
-      double v2 = 0.0;
+      double v = 0.0, v2 = 0.0;
       for (int i = i0 + lane; i < i1; i += 64 * 13) {
         double sv[13], kv[13];
 #pragma unroll
@@ -57,12 +58,12 @@ __device__ __forceinline__ void mlp_forward_body(const MlpDev& m, const double* 
       }
       v += v2;
       for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) tred[p * WPR + part_] = v;
     }
-    if (lane == 0) tred[wave] = v;
   }
   __syncthreads();
   if (theta_out != nullptr && tid < P) {               // the row's waves in a fixed order
-    const int WPR = MLP_PARTS / P;
+    const int WPR = MLP_PARTS / P > 0 ? MLP_PARTS / P : 1;
     double t = 0.0;
     for (int wv = 0; wv < WPR; ++wv) t += tred[tid * WPR + wv];
     theta_out[s * P + tid] = t;

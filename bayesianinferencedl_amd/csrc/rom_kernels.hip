@@ -854,11 +854,9 @@ int launch_rom_grad_contract(const RomDev& p, int64_t S, const RomGradArgs& ga, 
 template <bool IN_LDS, int NSET, bool FACTORED>
 static int launch_solve_t(const RomDev& p, size_t lds, const double* Ar, const double* Br, int64_t S, double* w_r,
                           double* qoi_r, double* Ar_out, double* Br_out, int* info, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET, FACTORED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_set = true;
-  }
+  static PerDeviceOnce once;                      // (per template instantiation, per device)
+  if (lds > 64 * 1024)
+    if (int rc = once.run([&]() -> int { FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET, FACTORED>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); return 0; })) return rc;
   hipLaunchKernelGGL((rom_solve_kernel<IN_LDS, NSET, FACTORED>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r, Ar_out, Br_out, info);
   FR_HIP(hipGetLastError());
   return 0;
@@ -867,11 +865,9 @@ static int launch_solve_t(const RomDev& p, size_t lds, const double* Ar, const d
 template <bool IN_LDS, int NSET>
 static int launch_grad_t(const RomDev& p, size_t lds, const double* Ar, const double* Br, int64_t S, double* w_r, double* qoi_r,
                          int* info, const RomGradArgs& ga, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-    attr_set = true;
-  }
+  static PerDeviceOnce once;
+  if (lds > 64 * 1024)
+    if (int rc = once.run([&]() -> int { FR_HIP(hipFuncSetAttribute((const void*)rom_solve_kernel<IN_LDS, NSET, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64)); return 0; })) return rc;
   hipLaunchKernelGGL((rom_solve_kernel<IN_LDS, NSET, true, true>), dim3((unsigned)S), dim3(64), lds, st, p, Ar, Br, S, w_r, qoi_r,
                      (double*)nullptr, (double*)nullptr, info, ga);
   FR_HIP(hipGetLastError());

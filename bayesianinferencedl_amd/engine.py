@@ -108,11 +108,11 @@ class _Batch:
 
 def _sync_if_mixed(b, other):
     """A torch-stream call that also consumed a NumPy operand staged through a pooled DeviceBuffer: the kernels may still be
-    running on torch's (non-blocking) stream when that buffer goes back to the free list and the next from_numpy overwrites
-    it on the null stream.  Synchronise the launch stream first (results of a pure NumPy call are copied back synchronously,
-    a pure torch call stages nothing)."""
-    if b.torch and not other.torch:
-        check(lib().finrom_stream_sync(b.stream), "finrom_stream_sync")
+    running on torch's (non-blocking) stream when that buffer goes back to the library's pool and its next owner writes it on the
+    default stream.  The staging buffer remembers the launch stream: it is parked behind an event recorded there
+    (finrom_free_async) and the next owner waits for that event -- no host synchronisation here."""
+    if b.torch and not other.torch and isinstance(other.keep, DeviceBuffer):
+        other.keep.used_on(b.stream)
 
 
 def _csr_rows(M):
@@ -356,7 +356,7 @@ class FomEngine:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().finrom_fom_destroy(self._h)
+            _ffi.destroy_handle("finrom_fom_destroy", self._h)
             self._h = None
 
     def __del__(self):
@@ -453,7 +453,7 @@ class RomEngine:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().finrom_rom_destroy(self._h)
+            _ffi.destroy_handle("finrom_rom_destroy", self._h)
             self._h = None
 
     def __del__(self):
@@ -475,6 +475,7 @@ class SubfinAverager:
         b = _Batch(K, self.n)
         th, tp = b.new((b.S, self.P))
         check(lib().finrom_subfin_avg(self._S.ptr, self.P, self.n, b.ptr, b.S, tp, b.stream), "finrom_subfin_avg")
+        self._S.used_on(b.stream)
         return b.out(th, (b.S, self.P))
 
     def on_device(self, K):
@@ -516,7 +517,7 @@ class FieldSampler:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().finrom_sampler_destroy(self._h)
+            _ffi.destroy_handle("finrom_sampler_destroy", self._h)
             self._h = None
 
     def __del__(self):
@@ -557,7 +558,7 @@ class DeviceErrorModel:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().finrom_mlp_destroy(self._h)
+            _ffi.destroy_handle("finrom_mlp_destroy", self._h)
             self._h = None
 
     def __del__(self):
@@ -581,6 +582,7 @@ def romml_grad(rom, mlp, Sop_buf, K, data):
     e, ep = b.new((S, n_obs), zero=False); info, ip = b.new((S,), "i4", zero=False)      # (finrom_romml_grad overwrites info)
     check(lib().finrom_romml_grad(rom._h, mlp._h, Sop_buf.ptr, b.ptr, db.ptr, per_sample, S, gp, lp, qp, ep, ip, b.stream),
           "finrom_romml_grad")
+    Sop_buf.used_on(b.stream)
     _sync_if_mixed(b, db)
     return {"grad": b.out(grad, (S, n)), "loss": b.out(loss, (S,)), "qoi_r": b.out(q, (S, n_obs)), "e_NN": b.out(e, (S, n_obs)),
             "info": b.out(info, (S,), "i4")}

@@ -150,9 +150,12 @@ class Fin:
         K = np.ascontiguousarray(K, dtype=np.float64).reshape(-1, ops.n); U = np.ascontiguousarray(U, dtype=np.float64).reshape(-1, ops.n)
         S = K.shape[0]
         d = np.broadcast_to(np.asarray(data, dtype=np.float64), (S, self.n_obs))
+        from .. import engine as _E
+        if not _E.USE_BAND or ops.band_plan() is None:       # (decided before any handle is created: the fallback needs no GPU)
+            return self._hessian_action_host(K, U, d)
         eng = self._engine("field")
-        if eng.band is None:
-            raise NotImplementedError("hessian_action needs the band sweep's stored factor (meshes with a band plan: m <= 20)")
+        if eng.band is None:                                 # the library was built without this mesh's window sizes
+            return self._hessian_action_host(K, U, d)
         Wm, B = ops.W_field, np.asarray(self.B_obs)
         fwd = eng.solve(K, want_w=True)
         if np.any(np.asarray(fwd["info"]) != 0):
@@ -166,6 +169,32 @@ class Fin:
         lam_hat = np.asarray(eng.solve_rhs(K, rhs2)["out"])[:, 0]
         rows = np.repeat(np.arange(ops.n), np.diff(ops.indptr)); cols = ops.indices
         return np.stack([Wm.T @ (lam_hat[s][rows] * w[s][cols]) + Wm.T @ (lam[s][rows] * w_hat[s][cols]) for s in range(S)])
+
+    def _hessian_action_host(self, K, U, d):
+        """The same four solves per sample with SciPy's SuperLU on the host -- what `hessian_action` was before the device path
+        (round 2) and what it stays for handles WITHOUT a band plan: meshes beyond the built-in window sizes (m >= 32),
+        FINROM_NO_BAND=1.  The reference's routine (:344-368) is a host routine that works on any mesh; this keeps that
+        property.  Never silent: a RuntimeWarning says that the diagnostic ran on the host."""
+        import warnings
+
+        import scipy.sparse.linalg as spl
+        warnings.warn("Fin.hessian_action: no band plan for this mesh / handle -- the four solves run on the host (SciPy SuperLU), "
+                      "not on the device", RuntimeWarning, stacklevel=3)
+        ops = self.ops
+        Wm, B, F = ops.W_field, np.asarray(self.B_obs), np.asarray(ops.F, dtype=np.float64)
+        rows = np.repeat(np.arange(ops.n), np.diff(ops.indptr)); cols = ops.indices
+        out = np.empty((K.shape[0], ops.n))
+        for s in range(K.shape[0]):
+            lu = spl.splu(ops.csr(ops.fom_values(K[s])).tocsc())
+            if not np.all(np.isfinite(lu.U.diagonal())) or np.any(lu.U.diagonal() == 0.0):
+                raise np.linalg.LinAlgError("FOM operator singular for this conductivity")
+            Au = ops.csr(Wm @ U[s])
+            w = lu.solve(F)
+            lam = lu.solve(-(B.T @ (B @ w - d[s])))
+            w_hat = lu.solve(-(Au @ w))
+            lam_hat = lu.solve(-(B.T @ (B @ w_hat)) - Au @ lam)
+            out[s] = Wm.T @ (lam_hat[rows] * w[cols]) + Wm.T @ (lam[rows] * w_hat[cols])
+        return out
 
     # ---- dense mass and stiffness matrices the reference keeps as attributes (:172-173; not used by the hot loop) ----------
     @property

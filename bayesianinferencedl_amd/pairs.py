@@ -41,6 +41,7 @@ class FinPairSolver:
         w, wp = (b.new((S, fom.n)) if want_w else (None, None))
         check(lib().finrom_solve_pairs(fom._h, rom._h, self._avg._S.ptr, b.ptr, S, qp, qrp, ep, wp, wrp, tp, ip, b.stream),
               "finrom_solve_pairs")
+        self._avg._S.used_on(b.stream)
         return {"qoi": b.out(qoi, (S, self.n_obs)), "qoi_r": b.out(qoi_r, (S, self.n_obs)),
                 "err": b.out(err, (S, self.n_obs)), "w": b.out(w, (S, fom.n)) if want_w else None,
                 "w_r": b.out(w_r, (S, rom.r)) if want_w_r else None, "theta": b.out(theta, (S, rom.P)), "info": b.out(info, (S,), "i4")}

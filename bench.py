@@ -109,12 +109,14 @@ def global_normal(seed, lo, hi, dim, block=1024):
     return out
 
 
-def flops_per_pair(ops, plan, rom, n_obs, P):
-    """SURVEY 8(d) formula, direct LSPG with the symmetric half of psi^T psi."""
+def flops_per_pair(ops, plan, rom, n_obs, P, field=False):
+    """SURVEY 8(d) formula, direct LSPG with the symmetric half of psi^T psi.  Assembly: 2 (P + 1) nnz for a parameter vector of P
+    entries (affine sum of P + 1 value tables), 21 ncells for a nodal field (per cell: mean of three nodal values, nine scaled
+    element entries added)."""
     n, r = ops.n, rom.n_r
     cc = np.diff(plan.col_ptr).astype(np.int64) + 1
     return {
-        "assembly": 2 * (P + 1) * ops.nnz,
+        "assembly": 21 * len(ops.mesh.cells) if field else 2 * (P + 1) * ops.nnz,
         "cholesky": int((cc * cc).sum()),
         "trisolves": 4 * plan.nnzL,
         "psi": 2 * ops.nnz * r,
@@ -336,7 +338,7 @@ def main():
 
     if rank == 0:
         ops, plan = V.operators(), solver._plan
-        fl = flops_per_pair(ops, plan, solver_r, pairs.n_obs, pairs.xdim)
+        fl = flops_per_pair(ops, plan, solver_r, pairs.n_obs, pairs.xdim, field=args.params == "field")
         total_pairs = world * S * args.steps
         ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in prof.items()}       # avg ms per launch
         launches = {k: v[0] for k, v in prof.items()}
@@ -563,16 +565,17 @@ def roofline(dom, ms, launches, S, args, ops, plan, solver, solver_r, pairs, fl)
 
     def hbm(bytes_per_sample, model):
         alg = per_launch * bytes_per_sample
-        traffic = measured_traffic(dom, key)
+        traffic, src = measured_traffic(dom, key)
         ach = alg / t / 1e9
         return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms[dom], "model": model}
+                "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": ms[dom], "model": model}
 
     def mfma(flops_per_sample, model):
         alg = per_launch * flops_per_sample
         ach = alg / t / 1e12
+        traffic, src = measured_traffic(dom, key)
         return {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": measured_traffic(dom, key), "algorithmic_flops_per_launch": alg,
+                "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_source": src, "algorithmic_flops_per_launch": alg,
                 "avg_launch_ms": ms[dom], "model": model}
 
     if dom == "rom_proj_mfma" and args.projection == "direct":
@@ -651,18 +654,21 @@ def dry_run(args, rank, world):
 
 def measured_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes of this same command on this workload (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs, tools/collect_profiles.sh -> profiles/r03_pmc_summary_<workload>.json); None if no
-    summary was taken on this workload."""
+    WRITE_SIZE collected in separate runs, tools/collect_profiles.sh -> profiles/rNN_pmc_summary_<workload>.json; the newest
+    round's summary for the workload wins) -> (bytes or None, source or None).  The counters cannot be collected inside a timed
+    run (rocprofv3 serialises the kernels), so the figure is a RECORD of the same command on the builder's box, not a measurement
+    of this run: `source` names the file and the commit it was taken at, and any other workload (sample count, sizes) gets None."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_pmc_summary_*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary_*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
-            if d.get("workload_key") == workload_key:
-                return d["hbm_bytes_per_launch"].get(kernel)
+            if d.get("workload_key") == workload_key and d["hbm_bytes_per_launch"].get(kernel) is not None:
+                return d["hbm_bytes_per_launch"][kernel], {"file": os.path.relpath(path, ROOT), "commit": d.get("commit"),
+                                                           "note": "rocprofv3 --pmc record of the same command (2 FETCH + WRITE, per launch); not collected in this run"}
         except Exception:
             continue
-    return None
+    return None, None
 
 
 def cpu_baseline(args, phi, Xs, res, pairs):

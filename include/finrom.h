@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 9
+#define FINROM_ABI_VERSION 10
 
 typedef enum {
   FINROM_OK = 0,
@@ -55,6 +55,25 @@ int finrom_device_count(int* count);
 int finrom_set_device(int ordinal);
 int finrom_malloc(void** dptr, size_t bytes);
 int finrom_free(void* dptr);
+/* Stream capture (HIP graphs).  Library calls may be captured (hmc.run_chains_device captures a whole HMC proposal around
+ * finrom_romml_grad), with two rules the library enforces itself: (1) while a capture is open on any stream the library knows
+ * of, it issues no hipFree / hipMalloc / synchronous call -- finrom_free and the *_destroy functions QUEUE their work (the
+ * handle is dead for the caller at once) and the next library call that finds no capture open runs the queue; finrom_malloc,
+ * the *_create functions, the synchronous copies and any call that would have to grow a handle's workspace fail with
+ * FINROM_ERR_UNSUPPORTED instead (run the call once with the same batch size before capturing); (2) a workspace that a captured
+ * call used is kept alive until its handle is destroyed, even if a later, larger call replaces it -- a replayed graph never
+ * points at freed memory (destroying the handle while its graph is still replayed remains the caller's error).
+ * The library learns of a capture from the streams it is handed: every entry point queries its `stream` argument, and
+ * finrom_note_stream(stream) tells it about a stream without doing anything else (returns 1 if that stream is capturing, else 0;
+ * the Python layer calls it with torch's current stream before it frees or destroys anything from a finaliser, which may run
+ * inside somebody's capture).  finrom_free_async(ptr, stream): as finrom_free for a buffer whose last user was a launch on
+ * `stream` -- the buffer is parked with an event recorded there and its next owner waits for that event (finrom_free assumes the
+ * last user has finished or ran on the default stream).  finrom_deferred_count: queued frees / destructions (tests);
+ * finrom_flush_deferred runs the queue if no capture is open and returns what is left. */
+int finrom_free_async(void* dptr, void* stream);
+int finrom_note_stream(void* stream);
+int finrom_deferred_count(void);
+int finrom_flush_deferred(void);
 int finrom_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
 int finrom_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
 int finrom_memset(void* dst, int value, size_t bytes, void* stream);

@@ -30,6 +30,16 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "pairs/s"
     assert d["config"]["failed_samples"] == 0
+    _flops_below_peak(d)
+    assert rf["traffic"] is None or (rf["traffic_source"] and rf["traffic_source"]["file"].startswith("profiles/"))
+
+
+def _flops_below_peak(d):
+    """config.flops_per_pair (SURVEY 8(d)'s formula for the form actually run) x samples / step time can never exceed the fp64
+    matrix peak (the field line once claimed 118 TFLOP/s because the affine-assembly term was charged per NODE)."""
+    S = d["config"]["samples_per_gpu"]
+    tflops = d["config"]["flops_per_pair"] * S / (d["ms_per_step"] * 1e-3) / 1e12
+    assert 0 < tflops <= 78.6, tflops
 
 
 @pytest.mark.parametrize("argv", [["--params", "nine", "--r", "120", "--samples", "4096"],
@@ -47,3 +57,4 @@ def test_bench_roofline_is_a_fraction_for_every_config(argv):
     assert rf is not None and 0 < rf["frac"] <= 1.0, rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel"] in d["kernels_avg_ms"] and "model" in rf
     assert d["config"]["failed_samples"] == 0
+    _flops_below_peak(d)

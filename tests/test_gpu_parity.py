@@ -747,14 +747,18 @@ def test_hessian_action_matches_differences_of_the_device_gradient(spaces, fom_s
     """Full Hessian action (four solves on the band sweep's stored factor, finrom_fom_solve_rhs) against central differences of the
     DEVICE adjoint gradient, and its Gauss-Newton part against `GN_hessian_action` (device Jacobian) when the data are reproduced
     exactly (zero residual)."""
-    if fom_schedule != "throughput schedule":
-        pytest.skip("the Hessian action's solves need the band plan this fixture mode leaves out")
+    import warnings
     from bayesianinferencedl_amd.fom.forward_solve import Fin
     fin = Fin(spaces(8))
     rng = np.random.default_rng(1)
     k = np.exp(0.3 * rng.standard_normal(fin.dofs)); u = rng.standard_normal(fin.dofs)
     d = rng.uniform(0.1, 1.0, fin.n_obs)
-    H = fin.hessian_action(k, u, d)
+    if fom_schedule != "throughput schedule":          # no band plan in this fixture mode: the host fallback, announced
+        with pytest.warns(RuntimeWarning, match="on the host"):
+            H = fin.hessian_action(k, u, d)
+        warnings.filterwarnings("ignore", category=RuntimeWarning, message="Fin.hessian_action")
+    else:
+        H = fin.hessian_action(k, u, d)
     eps = 1e-4
     fd = (fin.gradient(k + eps * u, d) - fin.gradient(k - eps * u, d)) / (2 * eps)
     assert np.linalg.norm(H - fd) < 1e-6 * np.linalg.norm(fd)
@@ -776,3 +780,65 @@ def test_wide_basis_fused_qoi_with_forty_observations(problems, spaces, r):
     assert (full["info"] == 0).all() and (qonly["info"] == 0).all()
     assert rel(qonly["qoi_r"], full["qoi_r"]) < TOL
     assert rel(full["qoi_r"], full["w_r"] @ rom.B_obs_phi.T) < TOL
+
+
+@pytest.mark.parametrize("m,r", [(12, 81), (12, 120), (20, 200)])
+def test_forty_point_observations_against_the_oracle(problems, spaces, m, r, fom_schedule):
+    """The 40 point observations of `external_obs=True` (fom/forward_solve.py:215-228, rom/averaged_affine_ROM.py:192-212;
+    SURVEY 8(d) cfg 4 quotes n_obs = 9 AND 40) against the oracle's own observation operator: the same boundary dofs, FOM and
+    reduced observables <= 1e-10 on samples from full blocks and from the tail block, in the full form (w / w_r returned) and
+    in the QoI-only forms -- for the FOM the full sweep with 40 rows of B_obs (two observations on one fin: the fins-as-functionals
+    form does not apply and must not be picked), for bases wider than 96 the three-tile-column epilogue [B_r | (B_obs Phi)^T]."""
+    from bayesianinferencedl_amd.fom.forward_solve import Fin
+    from bayesianinferencedl_amd.pairs import FinPairSolver
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    if m == 20 and fom_schedule != "throughput schedule":
+        pytest.skip("m = 20 without the band plan is the interpreter's case: covered at m = 12")
+    prob, V = problems(m), spaces(m)
+    fo = O.FinOracle(prob, external_obs=True)
+    assert fo.n_obs == 40 and len(np.unique(np.nonzero(fo.B_obs)[1])) > 30
+    phi = oracle_basis(prob, r, n_snap=r + 40)
+    ro = O.AffineROMOracle(prob, phi, B_obs=fo.B_obs)
+    fin = Fin(V, external_obs=True)
+    rom = AffineROMFin(V, None, phi, external_obs=True)
+    assert fin.n_obs == rom.n_obs == 40
+    assert np.array_equal(np.asarray(fin.B_obs), fo.B_obs) and np.array_equal(np.asarray(rom.B_obs), fo.B_obs)
+    assert np.max(np.abs(rom.B_obs_phi - ro.B_obs_phi)) == 0.0
+    S = 130                                                # two full blocks of 64 and a tail of two
+    idx = np.array([0, 1, 31, 63, 64, 100, 127, 128, 129])
+    K = np.exp(0.5 * np.random.default_rng(40).standard_normal((S, prob.n)))
+    W = np.array([fo.forward(K[i]) for i in idx])
+    Q = W @ fo.B_obs.T
+    WR = np.array([ro.forward_reduced(K[i]) for i in idx])
+    QR = WR @ ro.B_obs_phi.T
+    # FOM: with w and without (the pair path's request)
+    full = fin.forward_batch(K, want_w=True)
+    qo = fin.forward_batch(K, want_w=False)
+    eng = fin._engine("field")
+    if fom_schedule == "throughput schedule":
+        assert not eng.band_qoi_only, "40 point observations do not split by fins: the QoI-only sweep must not be installed"
+        assert eng.last_path() in ("band_registers", "band_lds_4wave")
+    assert (full["info"] == 0).all() and (qo["info"] == 0).all()
+    assert rel(full["w"][idx], W) < TOL and rel(full["qoi"][idx], Q) < TOL and rel(qo["qoi"][idx], Q) < TOL
+    assert np.array_equal(np.asarray(full["qoi"]), np.asarray(qo["qoi"]))
+    # ROM: w_r returned / only the reduced QoI (bases wider than 96: fused_solve_mw with three extra tile columns)
+    rw = rom.forward_reduced_batch(K)
+    rq = rom.forward_reduced_batch(K, want_w=False)
+    assert (rw["info"] == 0).all() and (rq["info"] == 0).all()
+    assert rel(rw["qoi_r"][idx], QR) < TOL and rel(rq["qoi_r"][idx], QR) < TOL
+    assert rel(rw["w_r"][idx] @ phi.T, WR @ phi.T) < TOL
+    # the sample-pair call: both halves + the error, 40 columns each
+    res = FinPairSolver(V, phi, True, "field", fin, rom).solve_pairs(K)
+    assert res["qoi"].shape == res["qoi_r"].shape == res["err"].shape == (S, 40) and (res["info"] == 0).all()
+    assert rel(res["qoi"][idx], Q) < TOL and rel(res["qoi_r"][idx], QR) < TOL
+    assert np.max(np.abs(res["err"] - (res["qoi"] - res["qoi_r"]))) == 0.0
+    # one-sample call patterns (batches <= 64 take other kernels): the scalar surface, and the per-fin parameter form
+    z = fin.forward(K[129])[0]
+    assert np.linalg.norm(fin.qoi_operator(z) - Q[-1]) < TOL * np.linalg.norm(Q[-1])
+    assert np.linalg.norm(rom.qoi_reduced(rom.forward_reduced(K[129])) - QR[-1]) < TOL * np.linalg.norm(QR[-1])
+    X9 = np.random.default_rng(41).uniform(0.1, 3.5, (70, 9))
+    p9 = FinPairSolver(V, phi, True, "nine", fin, rom).solve_pairs(X9)
+    for i in (0, 63, 64, 69):
+        k = fo.nine_param_to_function(X9[i])
+        q = fo.B_obs @ fo.forward(k); qr = ro.B_obs_phi @ ro.forward_reduced(k)
+        assert np.linalg.norm(p9["qoi"][i] - q) < TOL * np.linalg.norm(q) and np.linalg.norm(p9["qoi_r"][i] - qr) < TOL * np.linalg.norm(qr)
