@@ -86,11 +86,11 @@ int launch_subfin_avg(const double* Sop, int P, int n, const double* k, int64_t 
 }
 
 // k[s][j] = exp(0.5 * sum_{i<=j} xi[s][i] U[i][j])   (generate_fin_dataset.py:87-88; U upper)
-// fp64 MFMA GEMM, 64 x 64 output tile per workgroup, K-chunks of 16 through LDS; only the
+// Small batches (S < SAMPLER_GEMM_MIN_S): fp64 MFMA GEMM, 64 x 64 output tile per workgroup, K-chunks of 16 through LDS; only the
 // K-range i < j0+64 of the upper-triangular factor is visited.
-__global__ __launch_bounds__(256) void sampler_kernel(const double* __restrict__ U, int n,
-                                                      const double* __restrict__ xi, int64_t S,
-                                                      double* __restrict__ kout) {
+__global__ __launch_bounds__(256) void sampler_small_kernel(const double* __restrict__ U, int n,
+                                                            const double* __restrict__ xi, int64_t S,
+                                                            double* __restrict__ kout) {
   __shared__ double Xs[64][17];
   __shared__ double Us[16][65];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -136,13 +136,230 @@ __global__ __launch_bounds__(256) void sampler_kernel(const double* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The throughput form (round 4): C = Xi U as a blocked fp64-MFMA GEMM with the exp fused into the epilogue.
+//  * Workgroup = 8 waves = one 256 (samples) x 128 (columns) output tile; wave (wm, wn) owns 64 x 64 of it = 4 x 4 MFMA tiles,
+//    64 accumulator doubles per lane in ARCHITECTURAL VGPRs (inline-asm MFMA: the builtin's AGPR accumulators run at half rate,
+//    rom_proj_device.h), two waves per SIMD.
+//  * K in chunks of 16 through LDS, double-buffered, ONE `s_waitcnt lgkmcnt(0); s_barrier` per chunk; the operands of chunk c + 2
+//    are requested into registers while chunk c computes (no wait on them at the barrier).  LDS holds the chunk in OPERAND
+//    ORDER -- [k-step][16-row (col) tile][q][c] -- so a wave's operand fetch is one contiguous 512-B ds_read_b64: conflict-free.
+//    Per k-step a wave issues 16 MFMAs on 8 operand doubles (the 64 x 64 tile's intensity: 2 MFMAs per LDS double).
+//  * Workgroup tile traffic: (256 + 128) x K doubles per 256 x 128 x K multiply-adds -- 15 GB of L2 -> LDS traffic per 20 000
+//    samples at n = 4101 (round 3's 64 x 64 tiles: 41 GB, of which 30 GB reached HBM).  What keeps most of THAT in the XCD's 4 MiB
+//    L2: blocks b and b + 8 share an XCD (round-robin dispatch -- speed only, never correctness), and the 32 workgroups an XCD
+//    runs together are one SUPER-TILE of 4 sample tiles x 8 adjacent column tiles (1024 x 1024 outputs) that walk K in lockstep
+//    -- all 32 run to the super-tile's common K end (the top column tile's: U is zero below its diagonal, so the shorter tiles
+//    add exact zeros; ~17 % more MFMAs than the triangle needs, paid so that the tiles stay within the L2 window of each other):
+//    an Xi strip is then fetched from HBM once for 8 workgroups, a U strip once for 4.  Column groups are formed from the TOP
+//    (the lone leftover is column tile 0, K = 128) and super-tiles are dealt to the XCDs in descending K.
+// Same sums in the same order as sampler_small_kernel (k ascending in steps of four through the same instruction): bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int SG_TS = 80;                         // doubles between two operand tiles in LDS (64 + 16: rows 16 apart land on other banks when staged)
+// WM = wave rows of a workgroup: WM = 4 -> 256 x 128 tile, 8 waves, one workgroup per CU (120 KB of LDS); WM = 2 -> 128 x 128 tile,
+// 4 waves, TWO workgroups per CU (2 x 80 KB): the two waves of a SIMD then belong to different workgroups, and one workgroup's
+// per-chunk barrier and LDS hand-over are covered by the other's MFMAs.
+template <int WM> struct SGeo {
+  static constexpr int TM = 64 * WM, THREADS = 128 * WM;
+  static constexpr int A_BUF = 4 * (4 * WM) * SG_TS;        // [k-step][row tile] per buffer
+  static constexpr int B_BUF = 4 * 8 * SG_TS;               // [k-step][col tile]
+  static constexpr size_t LDS_BYTES = (size_t)2 * (A_BUF + B_BUF) * sizeof(double);
+  static constexpr int B_ITEMS = 512 / THREADS;             // 4-column items of the U chunk per thread
+  static constexpr int SM_PER_SUPER = 1024 / TM;            // sample tiles of a super-tile (1024 samples x 8 column tiles per XCD)
+};
+constexpr int64_t SAMPLER_GEMM_MIN_S = 4096;      // below: the 64 x 64 kernel fills the chip better
+
+#define SG_MFMA(ACC, A, B) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+
+template <int WM, int NT>      // NT = this wave's live column tiles (4; fewer only in the last column tile of a factor whose n is not a multiple of 128)
+__device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n, const double* __restrict__ xi, int64_t S,
+                                             double* __restrict__ kout, int64_t s0, int j0, int nch, double* lds) {
+  typedef SGeo<WM> G;
+  constexpr int SG_A_BUF = G::A_BUF, SG_B_BUF = G::B_BUF;
+  double* Abuf = lds;
+  double* Bbuf = lds + 2 * SG_A_BUF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int q = lane >> 4, c = lane & 15;
+  // staging: A = two items of 4 consecutive k for one row (4 lanes cover a row's 128 B), B = one item of 4 consecutive columns
+  const int a_row = tid >> 2, a_kq = tid & 3;
+  const int b_k = tid >> 5, b_j = (tid & 31) * 4;            // (+ THREADS / 32 rows per further item)
+  // Operand fetches are BUFFER loads (two 16-byte loads per item): rows beyond the batch / beyond the factor fall outside the
+  // resource and come back as zeros without a branch; the chunk offset rides in an SGPR.  (k >= n inside a row reads the head of
+  // the next row -- selected away below; columns j >= n of U read the next row of U and only feed output columns that are never
+  // stored.)
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  const int64_t rows_here = S - s0 < G::TM ? S - s0 : G::TM;
+  const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(xi + s0 * n), 0, (int)(rows_here * n * 8), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(U + j0), 0, (int)(((int64_t)n * n - j0) * 8), 0x00020000);
+  const int a_voff0 = (a_row * n + 4 * a_kq) * 8, a_voff1 = ((a_row + G::TM / 2) * n + 4 * a_kq) * 8;
+  const int b_voff = (b_k * n + b_j) * 8;
+  double ra[2][4], rb[G::B_ITEMS][4];
+  auto gload = [&](int ch) {
+    const int k0 = ch * 16;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int vo = it ? a_voff1 : a_voff0;
+      const d2_t lo = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(ares, vo, k0 * 8, 0));
+      const d2_t hi = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(ares, vo + 16, k0 * 8, 0));
+      ra[it][0] = lo[0]; ra[it][1] = lo[1]; ra[it][2] = hi[0]; ra[it][3] = hi[1];
+    }
+#pragma unroll
+    for (int it = 0; it < G::B_ITEMS; ++it) {
+      const int so = (k0 + it * (G::THREADS / 32)) * n * 8;
+      const d2_t lo = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(bres, b_voff, so, 0));
+      const d2_t hi = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(bres, b_voff + 16, so, 0));
+      rb[it][0] = lo[0]; rb[it][1] = lo[1]; rb[it][2] = hi[0]; rb[it][3] = hi[1];
+    }
+  };
+  auto lwrite = [&](int buf, int ch) {                                // (ch: the chunk the staging registers hold)
+    const int kk = ch * 16 + 4 * a_kq;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int row = a_row + (G::TM / 2) * it;
+      double* dst = Abuf + buf * SG_A_BUF + (a_kq * (4 * WM) + (row >> 4)) * SG_TS + (row & 15);
+      // (k >= n: the load wrapped into the next row -- zero it HERE, not where the load was issued: a select there would wait for
+      //  the load it should let fly for a whole chunk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dst[e * 16] = kk + e < n ? ra[it][e] : 0.0;            // e = q: the k inside the k-step
+    }
+#pragma unroll
+    for (int it = 0; it < G::B_ITEMS; ++it) {
+      const int bk = b_k + it * (G::THREADS / 32);
+      double* dstb = Bbuf + buf * SG_B_BUF + ((bk >> 2) * 8 + (b_j >> 4)) * SG_TS + (bk & 3) * 16 + (b_j & 15);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dstb[e] = rb[it][e];
+    }
+  };
+  auto exchange = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+
+  d4 acc[4][NT > 0 ? NT : 1];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int t = 0; t < (NT > 0 ? NT : 1); ++t) acc[i][t] = (d4){0.0, 0.0, 0.0, 0.0};
+  const double* Ard = Abuf + (4 * wm) * SG_TS + lane;
+  const double* Brd = Bbuf + (4 * wn) * SG_TS + lane;
+
+  gload(0);
+  lwrite(0, 0);
+  exchange();
+  if (nch > 1) gload(1);
+  for (int ch = 0; ch < nch; ++ch) {
+    const int cur = ch & 1;
+    const double* Ac = Ard + cur * SG_A_BUF;
+    const double* Bc = Brd + cur * SG_B_BUF;
+    double av[2][4], bv[2][NT > 0 ? NT : 1];
+    if constexpr (NT > 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[0][i] = Ac[i * SG_TS];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[0][t] = Bc[t * SG_TS];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if constexpr (NT > 0) {
+        if (ks < 3) {                                    // the next k-step's operands are on their way while this one's MFMAs issue
+#pragma unroll
+          for (int i = 0; i < 4; ++i) av[(ks + 1) & 1][i] = Ac[((ks + 1) * (4 * WM) + i) * SG_TS];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) bv[(ks + 1) & 1][t] = Bc[((ks + 1) * 8 + t) * SG_TS];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) SG_MFMA(acc[i][t], av[ks & 1][i], bv[ks & 1][t]);
+      }
+      if (ks == 1 && ch + 1 < nch) {                     // chunk ch + 1 (requested an iteration ago) goes to the other buffer ...
+        lwrite(cur ^ 1, ch + 1);
+        if (ch + 2 < nch) gload(ch + 2);                 // ... and chunk ch + 2 is requested: a whole chunk of MFMAs to arrive in
+      }
+    }
+    exchange();
+  }
+  if constexpr (NT > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (i == 0 && t == 0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[i][t]));
+        else asm volatile("" : "+v"(acc[i][t]));
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t s = s0 + 64 * wm + 16 * i + q + 4 * g;
+          const int j = j0 + 64 * wn + 16 * t + c;
+          if (s < S && j < n) kout[s * n + j] = exp(0.5 * acc[i][t][g]);
+        }
+  }
+}
+
+template <int WM>
+__global__ __launch_bounds__(128 * WM) void sampler_gemm_kernel(const double* __restrict__ U, int n, const double* __restrict__ xi,
+                                                              int64_t S, double* __restrict__ kout, int n_sgroups, int n_cgroups,
+                                                              int top_tile, int pad_k) {
+  extern __shared__ __attribute__((aligned(16))) double sg_lds[];
+  typedef SGeo<WM> G;
+  constexpr int WGS = 8 * G::SM_PER_SUPER;               // workgroups of a super-tile = what one XCD runs together (32 CUs)
+  // blocks b and b + 8 share an XCD: XCD-local sequence number -> (super-tile, slot); the super-tiles (descending K) are dealt to
+  // the XCDs boustrophedon -- 0..7, 7..0, ... -- so that no XCD always gets the longest of its round
+  const int b = blockIdx.x, xcd = b & 7, seq = b >> 3;
+  const int round = seq / WGS, slot = seq - round * WGS;
+  const int super = round * 8 + ((round & 1) ? 7 - xcd : xcd);
+  if (super >= n_sgroups * n_cgroups) return;
+  const int cg = super / n_sgroups, sgp = super - cg * n_sgroups;        // descending K: column group 0 is the top one
+  const int sm = slot >> 3, jn = slot & 7;
+  const int top = top_tile - 8 * cg, jt = top - 7 + jn;
+  if (jt < 0) return;
+  const int64_t s0 = ((int64_t)sgp * G::SM_PER_SUPER + sm) * G::TM;
+  if (s0 >= S) return;
+  const int j0 = jt * 128;
+  const int kend = min(n, ((pad_k ? top : jt) + 1) * 128);
+  const int nch = (kend + 15) / 16;
+  const int live = (n - j0 - 64 * ((int)(threadIdx.x >> 6) & 1) + 15) / 16;     // this wave's column tiles that hold columns < n
+  if (live >= 4) sampler_tile<WM, 4>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
+  else if (live == 3) sampler_tile<WM, 3>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
+  else if (live == 2) sampler_tile<WM, 2>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
+  else if (live == 1) sampler_tile<WM, 1>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
+  else sampler_tile<WM, 0>(U, n, xi, S, kout, s0, j0, nch, sg_lds);               // (stages and meets the barriers, no MFMAs)
+}
+
+template <int WM>
+static int launch_sampler_gemm(const double* U, int n, const double* xi, int64_t S, double* k, hipStream_t st, bool pad) {
+  typedef SGeo<WM> G;
+  static PerDeviceOnce once;
+  if (int rc = once.run([&]() -> int {
+        FR_HIP(hipFuncSetAttribute((const void*)sampler_gemm_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES));
+        return 0; })) return rc;
+  const int ntn = (n + 127) / 128, n_cgroups = (ntn + 7) / 8;
+  const int64_t n_sgroups = (S + 1023) / 1024, n_super = n_sgroups * n_cgroups;
+  if (n_sgroups > (1 << 20)) { set_error("sampler: batch too large for one launch"); return FINROM_ERR_UNSUPPORTED; }
+  const unsigned grid = (unsigned)((n_super + 7) / 8 * 8 * 8 * G::SM_PER_SUPER);
+  hipLaunchKernelGGL(sampler_gemm_kernel<WM>, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, st, U, n, xi, S, k, (int)n_sgroups, n_cgroups,
+                     ntn - 1, pad ? 1 : 0);
+  FR_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_sampler(const double* U, int n, const double* xi, int64_t S, double* k, hipStream_t st) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_SAMPLER, st);
-  dim3 grid((unsigned)((S + 63) / 64), (unsigned)((n + 63) / 64));
-  hipLaunchKernelGGL(sampler_kernel, grid, dim3(256), 0, st, U, n, xi, S, k);
-  FR_HIP(hipGetLastError());
-  return 0;
+  const char* env_min = getenv("FINROM_SAMPLER_GEMM_MIN");                   // (tests: force one kernel or the other)
+  const int64_t min_s = env_min ? atoll(env_min) : SAMPLER_GEMM_MIN_S;
+  if (S < min_s) {
+    dim3 grid((unsigned)((S + 63) / 64), (unsigned)((n + 63) / 64));
+    hipLaunchKernelGGL(sampler_small_kernel, grid, dim3(256), 0, st, U, n, xi, S, k);
+    FR_HIP(hipGetLastError());
+    return 0;
+  }
+  const bool no_pad = getenv("FINROM_SAMPLER_NO_PAD") != nullptr;            // (experiment: every tile stops at its own K end)
+  const char* env_wm = getenv("FINROM_SAMPLER_WM");                          // (A/B: 4 = 256-row tiles, one workgroup per CU)
+  if (env_wm && atoi(env_wm) == 4) return launch_sampler_gemm<4>(U, n, xi, S, k, st, !no_pad);
+  return launch_sampler_gemm<2>(U, n, xi, S, k, st, !no_pad);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -336,6 +336,21 @@ def main():
                          "per-sample psi^T psi contraction on fp64 MFMA (what the reference executes)"}
         solver_r.set_projection(args.projection)
 
+    # context only (Gaussian-field inputs): what drawing a fresh shard costs on top of the pair step -- xi by Philox on the device
+    # + k = exp(0.5 xi U) (finrom_sampler_draw_seeded); the timed region above works on a resident shard, as the contract asks
+    sampler_ms = None
+    if args.params == "field" and not args.no_profile:
+        like = torch.empty(0, device=dev, dtype=torch.float64)
+        sampler.draw(5, rank * S, S, like=like)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            sampler.draw(5, rank * S, S, like=like)
+        e1.record()
+        torch.cuda.synchronize()
+        sampler_ms = e0.elapsed_time(e1) / 3
+
     if rank == 0:
         ops, plan = V.operators(), solver._plan
         fl = flops_per_pair(ops, plan, solver_r, pairs.n_obs, pairs.xdim, field=args.params == "field")
@@ -374,6 +389,8 @@ def main():
             "process_group": {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced": bool(args.force_pg and world == 1)} if use_pg else None,
             "kernels_serial_ms": serial_ms,
             "host_io_pairs_per_s": host_io,
+            "sampler_ms_per_step": sampler_ms,
+            "value_incl_sampler": None if sampler_ms is None else world * S / (dt / args.steps + sampler_ms * 1e-3),
             "cpu_baseline_all_cores": cpu_all,
             "other_projection": other,
         }

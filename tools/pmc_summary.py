@@ -17,7 +17,8 @@ SLOT_OF = {"fom_band_kernel": "fom_chol_solve", "fom_band_ldsw_kernel": "fom_cho
            "rom_gram_store_kernel": "rom_proj_mfma", "fom_assemble_kernel": "fom_assemble", "rom_proj_kernel": "rom_proj_mfma",
            "rom_proj_lds_kernel": "rom_proj_mfma", "rom_proj_single_kernel": "rom_proj_mfma", "rom_solve_kernel": "rom_reduced_solve",
            "rom_chol_blocked_kernel": "rom_reduced_solve", "rom_subst_blocked_kernel": "rom_reduced_solve",
-           "subfin_avg_kernel": "subfin_avg", "subfin_avg_small_kernel": "subfin_avg", "pack_kernel": "pack", "sampler_kernel": "sampler_gemm_exp"}
+           "subfin_avg_kernel": "subfin_avg", "subfin_avg_small_kernel": "subfin_avg", "pack_kernel": "pack", "sampler_kernel": "sampler_gemm_exp", "sampler_gemm_kernel": "sampler_gemm_exp",
+           "sampler_small_kernel": "sampler_gemm_exp"}
 
 
 def kname(row):
