@@ -11,8 +11,26 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfinrom_hip.so")
-SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_wide.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "finrom_internal.h"), os.path.join(CSRC, "rom_proj_device.h"), os.path.join(CSRC, "fom_band_device.h"), os.path.join(ROOT, "include", "finrom.h")]
+SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_wide.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip", "hmc_kernels.hip", "comm.hip"]
+HEADERS = [os.path.join(CSRC, h) for h in ("finrom_core.h", "finrom_internal.h", "rom_proj_device.h", "fom_band_device.h", "mlp_device.h")] + [os.path.join(ROOT, "include", "finrom.h")]
+
+
+def _deps(path, seen=None):
+    """The source and every project header / source it includes with #include "...", recursively (csrc/ and include/): a change of
+    rom_proj_device.h does not rebuild the band sweep's translation units (minutes each)."""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as f:
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', f.read(), flags=re.M):
+            for d in (os.path.dirname(path), CSRC, os.path.join(ROOT, "include")):
+                q = os.path.join(d, inc)
+                if os.path.exists(q):
+                    _deps(q, seen)
+                    break
+    return seen
 FLAGS = ["--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + \
     os.environ.get("FINROM_EXTRA_FLAGS", "").split()      # (A/B builds of tuning constants, e.g. -DADJ_RING=2)
 # rom_proj_single.hip is built at -O2: at -O3 hipcc's extra passes inflate the register pressure of the r = 80 projection kernel
@@ -44,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [sp] + HEADERS + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])]):
+        if force or _stale(obj, sorted(_deps(sp)) + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(src, [])]):
             jobs.append([hipcc, *FLAGS, OPT.get(src, "-O3"), "-c", sp, "-o", obj])
 
     def run(cmd):
@@ -77,7 +95,7 @@ def build_asan() -> str:
     lib = os.path.join(LIBDIR, "libfinrom_hip_asan.so")
     san = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-omit-frame-pointer"]
     src = os.path.join(CSRC, "finrom_api.hip")
-    if _stale(obj, [src] + HEADERS):
+    if _stale(obj, sorted(_deps(src))):
         r = subprocess.run([hipcc, *FLAGS, "-O1", "-g", *san, "-c", src, "-o", obj], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc (asan) failed:\n" + r.stdout + r.stderr)

@@ -71,6 +71,14 @@ class MlpDesc(C.Structure):
                 ("Wh", c_f32p), ("bh", c_f32p)]
 
 
+class HmcState(C.Structure):
+    _fields_ = [("C", C.c_int64), ("n", C.c_int32), ("eps", C.c_double), ("c_lik", C.c_double), ("c_pri", C.c_double),
+                ("mean", C.c_void_p), ("K", C.c_void_p), ("U", C.c_void_p), ("dU", C.c_void_p),
+                ("Kq", C.c_void_p * 2), ("P", C.c_void_p), ("dUq", C.c_void_p), ("H0", C.c_void_p),
+                ("P_block", C.c_void_p), ("lu_block", C.c_void_p), ("jt", C.c_void_p), ("pt", C.c_void_p),
+                ("accept", C.c_void_p), ("trace", C.c_void_p), ("loss", C.c_void_p), ("info", C.c_void_p)]
+
+
 class RomDesc(C.Structure):
     _fields_ = [("n", C.c_int32), ("r", C.c_int32), ("P", C.c_int32), ("n_obs", C.c_int32),
                 ("nterms", C.c_int32),
@@ -128,6 +136,10 @@ SIGNATURES = {
     "finrom_mlp_destroy": (None, [C.c_void_p]),
     "finrom_mlp_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "finrom_romml_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 6),
+    "finrom_hmc_begin": (C.c_int, [C.POINTER(HmcState), C.c_void_p]),
+    "finrom_hmc_leapfrog": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(HmcState), C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "finrom_hmc_end": (C.c_int, [C.POINTER(HmcState), C.c_int32, C.c_void_p]),
     "finrom_solve_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 8),
     "finrom_sub": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "finrom_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -136,7 +148,7 @@ SIGNATURES = {
     "finrom_comm_destroy": (C.c_int, [C.c_void_p]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 # finrom_fom_last_path codes (include/finrom.h)
 FOM_PATHS = {0: "none", 1: "small_lds", 2: "small_global", 3: "interpreter", 4: "band_registers", 5: "band_lds_4wave",
              6: "band_lds_1wave", 7: "band_registers_qoi", 8: "band_lds_4wave_qoi"}

@@ -94,8 +94,130 @@ def romml_value_and_grad(solver_r):
     return f
 
 
+def run_chains_fused(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, sigma=0.05, tau=0.5, mean=None, record=None,
+                     keep_trace=False, graph=True, data=None, block=32):
+    """`run_chains_device` with the trajectory's arithmetic INSIDE the library (round 4: finrom_hmc_begin / _leapfrog / _end,
+    include/finrom.h): a leapfrog step is the four launches of finrom_romml_grad and nothing else -- the position update rides in
+    front of the contraction and the error model's forward pass, the momentum update behind the gradient -- and a proposal is
+    1 + 4 n_leapfrog + 2 launches, captured once and replayed.  Same random numbers, same order of evaluations and the same chains
+    as `run_chains` (the host recursion) up to the rounding of fused multiply-adds; same return value as `run_chains_device`.
+    Raises _ffi.FinromError (FINROM_ERR_UNSUPPORTED) where the library has no one-sample form for the model -- callers fall back to
+    `run_chains_device(..., fused=False)`."""
+    import ctypes as C
+    import torch
+    from .. import _ffi
+    L = _ffi.lib()
+    rom, mlp, Sop = solver_r._rom, solver_r._dev_model, solver_r._avg._S
+    if mlp is None:
+        raise _ffi.FinromError("run_chains_fused needs the error model on the device (a ResBnFcModel)")
+    solver_r._ensure_gradient()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    f64 = dict(dtype=torch.float64, device=dev)
+    i64 = dict(dtype=torch.int64, device=dev)
+    K = torch.as_tensor(np.ascontiguousarray(K0, dtype=np.float64), **f64).clone()
+    Cn, n = K.shape
+    mean_t = K.clone() if mean is None else torch.as_tensor(np.broadcast_to(np.asarray(mean, dtype=np.float64), (Cn, n)).copy(), **f64)
+    data_np = np.ascontiguousarray(solver_r.data if data is None else data, dtype=np.float64)
+    data_t = torch.as_tensor(data_np, **f64)
+    per_sample = 1 if data_np.ndim == 2 else 0
+    rngs = [np.random.default_rng(s) for s in seeds]
+    assert len(rngs) == Cn
+    c_lik, c_pri = 1.0 / sigma ** 2, 1.0 / tau ** 2
+    n_prop = max(0, (n_evals - 1) // n_leapfrog)
+    B = max(1, min(block, n_prop))
+    Kq = [torch.empty_like(K), torch.empty_like(K)]
+    P, dUq, dU = torch.zeros_like(K), torch.zeros_like(K), torch.zeros_like(K)
+    U, H0, loss = torch.zeros(Cn, **f64), torch.zeros(Cn, **f64), torch.zeros(Cn, **f64)
+    info = torch.zeros(Cn, dtype=torch.int32, device=dev)
+    P_dev, lu_dev = torch.zeros(B, Cn, n, **f64), torch.zeros(B, Cn, **f64)
+    jt, pt, acc = torch.zeros(1, **i64), torch.zeros(1, **i64), torch.zeros(Cn, **i64)
+    trace = torch.zeros(n_prop + 1, Cn, n, **f64) if keep_trace else None
+    grad_rec = torch.zeros_like(K)                                   # raw misfit gradient, written only for recorded evaluations
+    st = _ffi.HmcState(C=Cn, n=n, eps=eps, c_lik=c_lik, c_pri=c_pri, mean=mean_t.data_ptr(), K=K.data_ptr(), U=U.data_ptr(),
+                       dU=dU.data_ptr(), Kq=(C.c_void_p * 2)(Kq[0].data_ptr(), Kq[1].data_ptr()), P=P.data_ptr(), dUq=dUq.data_ptr(),
+                       H0=H0.data_ptr(), P_block=P_dev.data_ptr(), lu_block=lu_dev.data_ptr(), jt=jt.data_ptr(), pt=pt.data_ptr(),
+                       accept=acc.data_ptr(), trace=trace.data_ptr() if trace is not None else None, loss=loss.data_ptr(),
+                       info=info.data_ptr())
+    st0 = _ffi.HmcState.from_buffer_copy(st)                         # evaluation 0: a "step" of length zero from K itself
+    st0.eps = 0.0
+
+    def stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def leap(state, step, want_grad=False):
+        _ffi.check(L.finrom_hmc_leapfrog(rom._h, mlp._h, Sop.ptr, C.byref(state), step, data_t.data_ptr(), per_sample,
+                                         grad_rec.data_ptr() if want_grad else None, None, None, stream()), "finrom_hmc_leapfrog")
+        Sop.used_on(stream())
+
+    recorded, evals = [], 0
+
+    def note(step):
+        nonlocal evals
+        if record is not None and evals in record:
+            recorded.append((evals, Kq[(step + 1) & 1].cpu().numpy().copy(), loss.cpu().numpy().copy(), grad_rec.cpu().numpy().copy()))
+        evals += 1
+
+    def proposal(rec=False):
+        _ffi.check(L.finrom_hmc_begin(C.byref(st), stream()), "finrom_hmc_begin")
+        for i in range(n_leapfrog):                                  # each step's input depends on the previous gradient
+            leap(st, i, want_grad=rec)
+            if rec:
+                note(i)
+        _ffi.check(L.finrom_hmc_end(C.byref(st), n_leapfrog, stream()), "finrom_hmc_end")
+
+    # evaluation 0: the starting point (also warms the library up: workspaces, function attributes)
+    Kq[0].copy_(K)
+    leap(st0, 0, want_grad=True)                                     # Kq[1] = K + 0 * P, dUq = grad U / c_pri at K
+    note(0)
+    D = K - mean_t
+    Uv = torch.linalg.vecdot(D, D).mul_(0.5 * c_pri).add_(loss, alpha=c_lik)
+    U.copy_(torch.nan_to_num_(Uv, nan=float("inf"), posinf=float("inf"), neginf=float("inf")).masked_fill_(info.ne(0), float("inf")))
+    if not bool(torch.isfinite(U).all()):
+        raise ValueError("HMC start point has an indefinite reduced operator")
+    dU.copy_(dUq)
+    if trace is not None:
+        trace[0].copy_(K)
+    g = None
+    if graph and n_prop > 0:
+        state = [t.clone() for t in (K, U, dU, acc, jt, pt)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                               # warm-up on a side stream, as torch's graph recipe asks
+            proposal()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            proposal()
+        for t, t0 in zip((K, U, dU, acc, jt, pt), state):           # (the warm-up moved the state; the capture does not run)
+            t.copy_(t0)
+        if trace is not None:
+            trace[1].zero_()
+    done = 0
+    while done < n_prop:
+        nb = min(B, n_prop - done)
+        P_host, lu_host = np.zeros((B, Cn, n)), np.zeros((B, Cn))
+        for j in range(nb):                                         # the host chain's draws, in its order
+            for c_, r in enumerate(rngs):
+                P_host[j, c_] = r.standard_normal(n)
+            with np.errstate(divide="ignore"):
+                lu_host[j] = np.log(np.array([r.uniform() for r in rngs]))
+        P_dev.copy_(torch.from_numpy(P_host)); lu_dev.copy_(torch.from_numpy(lu_host))
+        jt.zero_()
+        for j in range(nb):
+            first = 1 + (done + j) * n_leapfrog
+            if record is not None and any(first <= e < first + n_leapfrog for e in record):
+                assert evals == first
+                proposal(rec=True)
+            else:
+                g.replay() if g is not None else proposal()
+                evals += n_leapfrog
+        done += nb
+    return HmcResult(K=K.cpu().numpy(), accept=acc.cpu().numpy(), proposals=n_prop, n_evals=evals, recorded=recorded,
+                     trace=trace.cpu().numpy() if trace is not None else None, graph=g is not None, fused=True)
+
+
 def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, sigma=0.05, tau=0.5, mean=None, record=None,
-                      keep_trace=False, graph=True, data=None, block=32):
+                      keep_trace=False, graph=True, data=None, block=32, fused=None):
     """`run_chains` with the chains RESIDENT ON THE DEVICE (torch tensors on the current CUDA device): positions, momenta,
     potentials, the Metropolis test and the accept counters never visit the host.  A whole PROPOSAL -- momentum in, n_leapfrog
     steps of (a few elementwise kernels around ONE library call, finrom_romml_grad on the tensors in place), Hamiltonians,
@@ -113,6 +235,16 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
     Same chains as run_chains(romml_value_and_grad(solver_r), ...) up to the rounding of the elementwise updates.
     Returns HmcResult(K [C, n] (NumPy), accept, proposals, n_evals, recorded, trace, graph: whether a graph was replayed)."""
     import torch
+    if fused is None or fused:
+        # the trajectory's arithmetic inside the library (round 4); fused=None: fall back to the torch-op form below where the
+        # library has no one-sample form for this model (FINROM_ERR_UNSUPPORTED)
+        from .. import _ffi
+        try:
+            return run_chains_fused(solver_r, K0, n_evals, seeds=seeds, eps=eps, n_leapfrog=n_leapfrog, sigma=sigma, tau=tau,
+                                    mean=mean, record=record, keep_trace=keep_trace, graph=graph, data=data, block=block)
+        except _ffi.FinromError:
+            if fused:
+                raise
     dev = torch.device("cuda", torch.cuda.current_device())
     f64 = dict(dtype=torch.float64, device=dev)
     K = torch.as_tensor(np.ascontiguousarray(K0, dtype=np.float64), **f64).clone()
@@ -234,4 +366,4 @@ def run_chains_device(solver_r, K0, n_evals, *, seeds, eps=2e-3, n_leapfrog=10, 
                 evals += n_leapfrog
         done += nb
     return HmcResult(K=K.cpu().numpy(), accept=acc.cpu().numpy(), proposals=n_prop, n_evals=evals, recorded=recorded,
-                     trace=trace.cpu().numpy() if trace is not None else None, graph=g is not None)
+                     trace=trace.cpu().numpy() if trace is not None else None, graph=g is not None, fused=False)

@@ -2,7 +2,7 @@
 // that do not bring torch.distributed -- a NumPy / ctypes caller in the reference's own style (deep_learning/generate_fin_dataset.py
 // :62-111 run per rank).  RCCL is loaded lazily with dlopen at the first finrom_comm_* call: the library has no link-time dependency
 // on librccl, single-GPU use never touches it, and a process that already holds an RCCL (PyTorch's) gets that same copy.
-#include "finrom_internal.h"
+#include "finrom_core.h"
 
 #include <cstring>
 #include <dlfcn.h>

@@ -1660,11 +1660,12 @@ int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, vo
   if (rc) return rc;
   return launch_mlp_forward(h->d, k, S, nullptr, 0, (float*)h->tape.p, e, nullptr, (hipStream_t)stream);
 }
-int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
-                      int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
-                      int32_t* info, void* stream) {
-  CallGuard cg((hipStream_t)stream);
-  if (!rom || !mlp || !Sop || S < 0 || (S > 0 && (!k || !data || !grad || !loss))) { set_error("romml_grad: bad argument"); return FINROM_ERR_ARG; }
+// (hs: the call is a leapfrog step -- finrom_hmc_leapfrog: position update in front, momentum update behind; one-sample form only)
+struct HmcStep { const double* mom; double eps; double* k_out; HmcTail tail; };
+static int romml_grad_impl(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
+                           int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
+                           int32_t* info, void* stream, const HmcStep* hs) {
+  if (!rom || !mlp || !Sop || S < 0 || (S > 0 && (!k || !data || (!grad && !hs) || !loss))) { set_error("romml_grad: bad argument"); return FINROM_ERR_ARG; }
   const MlpDev& m = mlp->d;
   if (m.n_out != rom->d.n_obs) { set_error("romml_grad: the error model's outputs are not the ROM's observables"); return FINROM_ERR_ARG; }
   if (S == 0) return 0;
@@ -1687,7 +1688,12 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
   // on this runtime: 113 -> 355 us, tools/graph_call_cost.py.)
   const bool one = rom->projection == FINROM_PROJECTION_DIRECT && rom_onesample_applies(rom->d, S) && getenv("FINROM_OLD_SUBST") == nullptr &&
                    rom->g_npairs > 0;
+  if (hs != nullptr && !(one && P <= 16)) {
+    set_error("hmc_leapfrog: needs the one-sample form of the reduced model (<= 64 chains, direct projection, r <= 96, <= 16 averages, finrom_rom_set_gradient)");
+    return FINROM_ERR_UNSUPPORTED;
+  }
   MlpFuse fm;
+  if (hs != nullptr) { fm.mom = hs->mom; fm.eps = hs->eps; fm.k_out = hs->k_out; }
   if (one && P <= 16) {                                // the network's forward pass and theta = S k ride in the ROM's contraction kernel
     fm.on = 1; fm.m = m; fm.k = k; fm.data = data; fm.data_stride = stride; fm.tape = (float*)mlp->tape.p; fm.e_out = e_nn;
     fm.data_shift = (double*)mlp->shift.p;
@@ -1718,7 +1724,53 @@ int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, con
     return FINROM_ERR_UNSUPPORTED;
   }
   return launch_mlp_backward(m, S, (const float*)mlp->tape.p, data, stride, qoi_r, e_nn, (const double*)mlp->gth.p, Sop, P, grad, st,
-                             gparts, gparts ? ROM_GRAD_SMALL_NG : 0, bf.on && gparts ? (const float*)mlp->g0.p : nullptr);
+                             gparts, gparts ? ROM_GRAD_SMALL_NG : 0, bf.on && gparts ? (const float*)mlp->g0.p : nullptr,
+                             hs != nullptr ? &hs->tail : nullptr);
+}
+
+int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
+                      int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
+                      int32_t* info, void* stream) {
+  CallGuard cg((hipStream_t)stream);
+  return romml_grad_impl(rom, mlp, Sop, k, data, data_per_sample, S, grad, loss, qoi_r, e_nn, info, stream, nullptr);
+}
+
+static int hmc_dev(const finrom_hmc_state* a, HmcDev* h, const char* who) {
+  if (!a || a->C < 0 || a->n <= 0 || !a->mean || !a->K || !a->U || !a->dU || !a->Kq[0] || !a->Kq[1] || !a->P || !a->dUq || !a->H0 ||
+      !a->P_block || !a->lu_block || !a->jt || !a->pt || !a->accept || !a->loss || !a->info) {
+    set_error(std::string(who) + ": null field in finrom_hmc_state"); return FINROM_ERR_ARG;
+  }
+  h->C = a->C; h->n = a->n; h->eps = a->eps; h->c_lik = a->c_lik; h->c_pri = a->c_pri;
+  h->mean = a->mean; h->K = a->K; h->U = a->U; h->dU = a->dU; h->Kq0 = a->Kq[0]; h->P = a->P; h->dUq = a->dUq; h->H0 = a->H0;
+  h->P_block = a->P_block; h->lu_block = a->lu_block; h->jt = (long long*)a->jt; h->pt = (long long*)a->pt;
+  h->accept = (long long*)a->accept; h->trace = a->trace; h->loss = a->loss; h->info = a->info;
+  return 0;
+}
+int finrom_hmc_begin(const finrom_hmc_state* a, void* stream) {
+  CallGuard cg((hipStream_t)stream);
+  HmcDev h;
+  if (int rc = hmc_dev(a, &h, "hmc_begin")) return rc;
+  return launch_hmc_begin(h, (hipStream_t)stream);
+}
+int finrom_hmc_end(const finrom_hmc_state* a, int32_t n_steps, void* stream) {
+  CallGuard cg((hipStream_t)stream);
+  HmcDev h;
+  if (int rc = hmc_dev(a, &h, "hmc_end")) return rc;
+  if (n_steps < 0) { set_error("hmc_end: n_steps < 0"); return FINROM_ERR_ARG; }
+  return launch_hmc_end(h, a->Kq[n_steps & 1], (hipStream_t)stream);       // (the position ping-pongs once per step)
+}
+int finrom_hmc_leapfrog(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const finrom_hmc_state* a, int32_t step,
+                        const double* data, int32_t data_per_sample, double* grad_out, double* qoi_r, double* e_nn, void* stream) {
+  CallGuard cg((hipStream_t)stream);
+  HmcDev h;
+  if (int rc = hmc_dev(a, &h, "hmc_leapfrog")) return rc;
+  if (!mlp || a->n != mlp->d.n_in || step < 0) { set_error("hmc_leapfrog: bad argument"); return FINROM_ERR_ARG; }
+  if (a->c_pri == 0.0) { set_error("hmc_leapfrog: c_pri = 0"); return FINROM_ERR_ARG; }
+  HmcStep hs;
+  hs.mom = a->P; hs.eps = a->eps; hs.k_out = a->Kq[(step + 1) & 1];
+  hs.tail.on = 1; hs.tail.kq = hs.k_out; hs.tail.mean = a->mean; hs.tail.mom = a->P; hs.tail.dU = a->dUq;
+  hs.tail.coef = a->c_lik / a->c_pri; hs.tail.eps_cpri = a->eps * a->c_pri; hs.tail.info = a->info;
+  return romml_grad_impl(rom, mlp, Sop, a->Kq[step & 1], data, data_per_sample, a->C, grad_out, a->loss, qoi_r, e_nn, a->info, stream, &hs);
 }
 
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {

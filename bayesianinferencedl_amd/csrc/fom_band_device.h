@@ -2,7 +2,7 @@
 // fom_band_adjoint.hip: the adjoint gradient on the same workspace layout): compile-time loops, the workspace as a buffer
 // resource, the extras' LDS layout, the backward sweep.  See fom_band.hip for the algorithm.
 #pragma once
-#include "finrom_internal.h"
+#include "finrom_core.h"
 #include <type_traits>
 
 namespace finrom {

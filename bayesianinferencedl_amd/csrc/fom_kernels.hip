@@ -13,7 +13,7 @@
 // interpreted by fom_vm_kernel; the "a" operand of a multiply-add comes from an LDS cache of the
 // row being eliminated, the "b" operand from global memory, fetched one 8-op chunk ahead.
 // Bound: HBM/L2 bandwidth (one 8-B load per multiply-add and sample, no reuse in registers).
-#include "finrom_internal.h"
+#include "finrom_core.h"
 #include <type_traits>
 
 namespace finrom {

@@ -27,7 +27,9 @@ __device__ __forceinline__ void mlp_forward_body(const MlpDev& m, const double* 
                                                  const double* __restrict__ data, int64_t data_stride,
                                                  float* __restrict__ tape, double* __restrict__ e_out,
                                                  double* __restrict__ data_shift, const double* __restrict__ Sop, int P,
-                                                 double* __restrict__ theta_out, float* __restrict__ xs, int tid) {
+                                                 double* __restrict__ theta_out, float* __restrict__ xs, int tid,
+                                                 const double* __restrict__ mom = nullptr, double eps = 0.0,
+                                                 double* __restrict__ k_out = nullptr) {
   constexpr int MLP_PARTS = NTHR / 64;                 // threads per hidden unit in the first layer
   constexpr int MLP_THREADS = NTHR;
   constexpr int CH = NTHR >= 1024 ? 32 : 128;          // first-layer loads in flight per thread (fewer threads: deeper batches)
@@ -35,7 +37,15 @@ __device__ __forceinline__ void mlp_forward_body(const MlpDev& m, const double* 
   __shared__ float y[MLP_MAX_W], a[MLP_MAX_W];
   __shared__ double tred[MLP_PARTS > 16 ? MLP_PARTS : 16];      // (P <= 16: finrom_romml_grad)
   const int nw = m.n_w;
-  for (int i = tid; i < m.n_in; i += MLP_THREADS) xs[i] = (float)k[s * m.n_in + i];
+  if (mom != nullptr) {                                // the leapfrog's position update in front: k + eps * mom, written to k_out
+    for (int i = tid; i < m.n_in; i += MLP_THREADS) {
+      const double kd = fma(eps, mom[s * m.n_in + i], k[s * m.n_in + i]);
+      xs[i] = (float)kd;
+      if (k_out != nullptr) k_out[s * m.n_in + i] = kd;
+    }
+  } else {
+    for (int i = tid; i < m.n_in; i += MLP_THREADS) xs[i] = (float)k[s * m.n_in + i];
+  }
   if (theta_out != nullptr) {
     // theta_p = sum_i Sop[p][i] k[i] in fp64: row p belongs to the waves p WPR .. p WPR + WPR - 1 (WPR = 16 / P: three waves per row
     // for five averages), a wave's slice dealt over its lanes in coalesced passes of 64, 13 passes requested at a time; ONE

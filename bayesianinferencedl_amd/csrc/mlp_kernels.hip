@@ -39,7 +39,7 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
                                                            const double* __restrict__ qoi_r, const double* __restrict__ e_nn,
                                                            const double* __restrict__ g_theta, const double* __restrict__ Sop,
                                                            int P, double* __restrict__ grad, const double* __restrict__ g_parts,
-                                                           int n_parts, const float* __restrict__ g0_in) {
+                                                           int n_parts, const float* __restrict__ g0_in, HmcTail ht) {
   __shared__ float g[MLP_MAX_W], up[MLP_MAX_W];
   __shared__ double gth[32];
   const int64_t s = blockIdx.x;
@@ -85,7 +85,13 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
     }
     double out = -(double)acc;                         // d loss / d input = -vjp(r)
     for (int p = 0; p < P; ++p) out = fma(gth[p], Sop[(int64_t)p * m.n_in + i], out);
-    grad[s * m.n_in + i] = out;
+    if (grad != nullptr) grad[s * m.n_in + i] = out;
+    if (ht.on) {                                       // the leapfrog's momentum update behind the gradient (finrom_hmc_leapfrog)
+      const int64_t idx = s * m.n_in + i;
+      const double du = ht.info[s] != 0 ? 0.0 : fma(ht.coef, out, ht.kq[idx] - ht.mean[idx]);
+      ht.dU[idx] = du;
+      ht.mom[idx] = fma(-ht.eps_cpri, du, ht.mom[idx]);
+    }
   }
 }
 
@@ -102,15 +108,16 @@ int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double
 
 int launch_mlp_backward(const MlpDev& m, int64_t S, const float* tape, const double* data, int64_t data_stride, const double* qoi_r,
                         const double* e_nn, const double* g_theta, const double* Sop, int P, double* grad, hipStream_t st,
-                        const double* g_parts, int n_parts, const float* g0_in) {
+                        const double* g_parts, int n_parts, const float* g0_in, const HmcTail* tail) {
   if (S == 0) return 0;
   ScopedKernelTimer t(K_MISC, st);
+  const HmcTail ht = tail != nullptr ? *tail : HmcTail();
   if (S <= MLP_SPLIT_MAX_S)
     hipLaunchKernelGGL(mlp_backward_kernel<MLP_SPLIT>, dim3((unsigned)S, MLP_SPLIT), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride,
-                       qoi_r, e_nn, g_theta, Sop, P, grad, g_parts, n_parts, g0_in);
+                       qoi_r, e_nn, g_theta, Sop, P, grad, g_parts, n_parts, g0_in, ht);
   else
     hipLaunchKernelGGL(mlp_backward_kernel<1>, dim3((unsigned)S), dim3(MLP_THREADS), 0, st, m, S, tape, data, data_stride, qoi_r, e_nn,
-                       g_theta, Sop, P, grad, g_parts, n_parts, g0_in);
+                       g_theta, Sop, P, grad, g_parts, n_parts, g0_in, ht);
   FR_HIP(hipGetLastError());
   return 0;
 }

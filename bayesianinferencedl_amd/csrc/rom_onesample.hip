@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
   // depend on -- as a kernel of its own it was 19 us at the head of the one-sample call, here it ends with the contraction
   if (fm.on && j == NC) {
     mlp_forward_body<256>(fm.m, fm.k, s, fm.data, fm.data_stride, fm.tape, fm.e_out, fm.data_shift, nullptr, 0, nullptr,
-                          (float*)red_lds, (int)threadIdx.x);
+                          (float*)red_lds, (int)threadIdx.x, fm.mom, fm.eps, fm.k_out);
     return;
   }
   const int q = lane >> 4, c = lane & 15;
@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
     __shared__ double th_part[4][16];
     const int n = fm.m.n_in, P = fm.P;
     const double* __restrict__ krow = fm.k + s * (int64_t)n;
+    const double* __restrict__ mrow = fm.mom != nullptr ? fm.mom + s * (int64_t)n : nullptr;      // (leapfrog: the field is k + eps * mom)
     const int i0 = (int)((int64_t)n * wave / 4), i1 = (int)((int64_t)n * (wave + 1) / 4);
     double tacc[16];
 #pragma unroll
@@ -62,6 +63,10 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
       double kv[TU], sv[16][TU];
 #pragma unroll
       for (int u = 0; u < TU; ++u) kv[u] = ib + 64 * u < i1 ? krow[ib + 64 * u] : 0.0;
+      if (mrow != nullptr) {
+#pragma unroll
+        for (int u = 0; u < TU; ++u) kv[u] = ib + 64 * u < i1 ? fma(fm.eps, mrow[ib + 64 * u], kv[u]) : 0.0;
+      }
 #pragma unroll
       for (int pp = 0; pp < 16; ++pp)
         if (pp < P) {
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
 typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4d mma(double a, double b, v4d cacc) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cacc, 0, 0, 0); }
 
-template <int NB> constexpr int small_solve_lds() { return onesample_nt<NB>() * 256 + NB * 256 + 16 * NB + 32 + 32; }
+template <int NB> constexpr int small_solve_lds() { return onesample_nt<NB>() * 256 + 2 * NB * 256 + 16 * NB + 32 + 32; }
 
 template <int NB>
 __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const double* __restrict__ theta, int64_t S, int NC,
@@ -143,7 +148,8 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* __restrict__ tl = lds;                      // [NT][256] A tiles, overwritten by U tiles; natural layout (row * 16 + col)
   double* __restrict__ mbuf = tl + NT * 256;          // [NB][256] M_kb, natural layout
-  double* __restrict__ bl = mbuf + NB * 256;          // [16 NB] B_r
+  double* __restrict__ zl = mbuf + NB * 256;          // [NB][256] the extra tile column Z, natural layout
+  double* __restrict__ bl = zl + NB * 256;            // [16 NB] B_r
   double* __restrict__ th = bl + 16 * NB;             // [32] 1, theta_1..P, 0
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t s = blockIdx.x;
@@ -193,13 +199,12 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
     if (lane < p.P) th[lane + 1] = theta[s * p.P + lane];
   }
   __syncthreads();
-  if (wave > 0) return;
 #ifdef FINROM_SOLVE_CLOCKS
   ck[1] = wall_clock64();
 #endif
 
-  // B_r = psi^T F (rom :297): F is non-zero on the root nodes only; their rows of psi are rebuilt here
-  {
+  // B_r = psi^T F (rom :297): F is non-zero on the root nodes only; their rows of psi are rebuilt here (wave 0)
+  if (wave == 0) {
     double bacc[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) bacc[b] = 0.0;
@@ -226,149 +231,158 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
       if (q == 0) bl[16 * b + c] = x;
     }
   }
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
 #ifdef FINROM_SOLVE_CLOCKS
   ck[2] = wall_clock64();
 #endif
 
   auto tile_at = [&](int ti, int tj) -> double* { return tl + (ti * NB - (ti * (ti - 1)) / 2 + (tj - ti)) * 256; };
+  // column NB = the extra tile column G = [B_r | (B_obs Phi)^T] -> Z: its tile of block row j lives at zl + 256 j
+  auto col_tile = [&](int ti, int tj) -> double* { return tj < NB ? tile_at(ti, tj) : zl + ti * 256; };
   const __amdgpu_buffer_rsrc_t ores = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.obs_phi), 0, p.n_obs * p.r * 8, 0x00020000);
   const int ovoff = ((c - 1) * p.r + q) * 8;            // row q of observation c - 1 (c == 0 and c > n_obs: out of range, reads 0)
   const int nat = q * 16 + c, trn = c * 16 + q;         // natural / transposed offset of element (q, c) inside a tile: + 64 g / + 4 g
   int bad = 0;
-  v4d z[NB];
-  // ---- forward ---------------------------------------------------------------------------------------------------------------
+  // ---- forward (round 4: over the four waves) ---------------------------------------------------------------------------------
+  // Round 3 walked the block rows on wave 0 alone: ~400 dependent-issue MFMAs of 64 cycles each on one SIMD while three waves had
+  // left.  Now, per block row kb: wave 0 owns the DIAGONAL tile (left-looking sum, then diag_tile_inverse -> M_kb to LDS); the
+  // tiles right of it and the extra column are dealt over waves 1 .. 3 (at most two each), which form their left-looking sums
+  // T(kb, tj) = A(kb, tj) - sum_{j < kb} U(j, kb)^T U(j, tj) meanwhile, wait for M_kb at ONE barrier, turn their tiles into
+  // U(kb, tj) = M_kb T(kb, tj) (Z_kb for the extra column) and hand them over through LDS at a second barrier.  Same sums in the
+  // same order as before (an accumulator's terms j = 0 .. kb - 1, k-steps g = 0 .. 3): bit-identical.
   sfor<0, NB>([&](auto kc) {
     constexpr int kb = decltype(kc)::value;
-    v4d T[NB - kb];
-    sfor<kb, NB>([&](auto jc) {
-      constexpr int tj = decltype(jc)::value;
-      const double* at = tile_at(kb, tj);
+    constexpr int NITEM = NB - kb;                       // tiles tj = kb + 1 .. NB - 1 and the extra column tj = NB
+    v4d T[2];
+    int tjs[2];
+    if (wave == 0) {
+      v4d D;
+      const double* at = tile_at(kb, kb);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) T[tj - kb][g] = at[nat + 64 * g];
-    });
-    v4d e;
+      for (int g = 0; g < 4; ++g) D[g] = at[nat + 64 * g];
+      // padding rows / columns (>= r) of psi^T psi are zero: unit diagonal (kb >= 2: the look-ahead has done it)
+      if constexpr (kb < 2) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row = 16 * kb + q + 4 * g;
-      double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ores, ovoff, (16 * kb + 4 * g) * 8, 0));
-      if (row >= p.r) v = 0.0;
-      if (c == 0) v = bl[row];
-      e[g] = v;
-    }
-    // padding rows / columns (>= r) of psi^T psi are zero: unit diagonal
+        for (int g = 0; g < 4; ++g)
+          if (q + 4 * g == c && 16 * kb + c >= p.r) D[g] = 1.0;
+      }
+      if constexpr (kb > 0) {
+        // (kb >= 2: the terms j < kb - 1 were subtracted a block row ago by the look-ahead below, in place; the newest row's is left)
+        constexpr int j0 = kb >= 2 ? kb - 1 : 0;
+        double ua[kb][4];
+        sfor<j0, kb>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const double* ujk = tile_at(j, kb);
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      if (q + 4 * g == c && 16 * kb + c >= p.r) T[0][g] = 1.0;
-    // left-looking: minus what the block rows above contribute (their U tiles in LDS, natural layout = the operand layouts)
-    // (every operand of the block row is requested from LDS before the first MFMA: left to the compiler, most MFMAs waited for
-    // their own ds_read)
-    if constexpr (kb > 0) {
-      double ua[kb][4], ub[kb][NB - kb][4];
-      sfor<0, kb>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const double* ujk = tile_at(j, kb);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ua[j][g] = -ujk[nat + 64 * g];      // A operand of k-step g: U(j, kb)[k = q + 4 g][i = c]
-        sfor<kb, NB>([&](auto tc) {
-          constexpr int tj = decltype(tc)::value;
-          const double* ujt = tile_at(j, tj);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) ub[j][tj - kb][g] = ujt[nat + 64 * g];
+          for (int g = 0; g < 4; ++g) ua[j][g] = ujk[nat + 64 * g];
         });
-      });
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      sfor<0, kb>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
+        sfor<j0, kb>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          sfor<kb, NB>([&](auto tc) {
-            constexpr int tj = decltype(tc)::value;
-            T[tj - kb] = mma(ua[j][g], ub[j][tj - kb][g], T[tj - kb]);
-          });
-          e = mma(ua[j][g], z[j][g], e);
-        }
-      });
-    }
-    // (a) the diagonal tile: 16 elimination steps on [T_kk | I]; M^T is carried (column operations), which is M as an A operand
-    // (The 16 shuffle steps this used to be -- kept behind FINROM_DIAG_SHUFFLE -- were what the sweep spent its time on: ~450 cycles per
-    // pivot, 96 pivots.  Not a latency chain -- taking the pivots off the vector update (p_{k+1} = D[k+1][k+1] - D[k+1][k]^2 / p_k
-    // from three v_readlanes, reciprocal instead of 1/sqrt on the chain) made it 6 % SLOWER -- but issue: one wave alone on its
-    // SIMD issues an instruction every >= 4 cycles and a step was ~100 of them, twelve ds_bpermutes among them.)
-    double Am[4];
+          for (int g = 0; g < 4; ++g) D = mma(-ua[j][g], ua[j][g], D);
+        });
+      }
 #ifdef FINROM_SOLVE_CLOCKS
-    const long long cd0 = wall_clock64();
+      const long long cd0 = wall_clock64();
 #endif
-#ifndef FINROM_DIAG_SHUFFLE
-    {
-      // (4 x 4-blocked factorisation on the matrix cores: diag_tile_inverse, rom_proj_device.h)
-      const v4d Mc = diag_tile_inverse(T[0], q, c, lane, bad);
-      // M_kb in its natural layout for the backward sweep, and back as the A operand of M T: Am[g] at lane (q, c) is M[c][q + 4 g]
+      const v4d Mc = diag_tile_inverse(D, q, c, lane, bad);      // (4 x 4-blocked factorisation on the matrix cores, rom_proj_device.h)
+      // M_kb in its natural layout: the backward sweep's operand, and (read transposed) the A operand of M T
 #pragma unroll
       for (int g = 0; g < 4; ++g) mbuf[kb * 256 + nat + 64 * g] = Mc[g];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int g = 0; g < 4; ++g) Am[g] = mbuf[kb * 256 + trn + 4 * g];
-    }
 #ifdef FINROM_SOLVE_CLOCKS
-    ck[6] += wall_clock64() - cd0;
+      ck[6] += wall_clock64() - cd0;
 #endif
-#else
-    {
-      v4d& D = T[0];
+    } else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) Am[g] = (q + 4 * g == c) ? 1.0 : 0.0;
+      for (int sl = 0; sl < 2; ++sl) {
+        const int item = (wave - 1) + 3 * sl;            // 0 .. NITEM - 1
+        const int tj = kb + 1 + item;                    // (tj == NB: the extra column)
+        tjs[sl] = item < NITEM ? tj : -1;
+        if (item >= NITEM) continue;
+        if (tj < NB) {
+          const double* at = tile_at(kb, tj);
 #pragma unroll
-      for (int gs = 0; gs < 4; ++gs)
-#pragma unroll
-        for (int qs = 0; qs < 4; ++qs) {
-          const int st = 4 * gs + qs;
-          const double piv = read_lane_f64(D[gs], qs * 16 + st);
-          bad |= !(piv > 0.0);
-          double rinv = __builtin_amdgcn_rsq(piv);
-#pragma unroll
-          for (int it = 0; it < 2; ++it) rinv = rinv * fma(-0.5 * piv * rinv, rinv, 1.5);
-          D[gs] *= (q == qs) ? rinv : 1.0;
-          const double rvD = __shfl(D[gs], qs * 16 + c);
-          const double mcol = (c > st) ? rvD : 0.0, scol = (c == st) ? rinv : 1.0;
+          for (int g = 0; g < 4; ++g) T[sl][g] = at[nat + 64 * g];
+        } else {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            if (g <= gs) {
-              Am[g] *= scol;
-              Am[g] = fma(-mcol, __shfl(Am[g], q * 16 + st), Am[g]);
-            }
-            if (g >= gs) {
-              const double v = __shfl(D[gs], qs * 16 + ((q + 4 * g) & 15));
-              const double m = (q + 4 * g > st) ? v : 0.0;
-              D[g] = fma(-m, rvD, D[g]);
-            }
+            const int row = 16 * kb + q + 4 * g;
+            double v = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(ores, ovoff, (16 * kb + 4 * g) * 8, 0));
+            if (row >= p.r) v = 0.0;
+            if (c == 0) v = bl[row];
+            T[sl][g] = v;
           }
         }
+        if constexpr (kb > 0) {
+          // every operand of the tile is requested from LDS before the first MFMA
+          double ua[kb][4], ub[kb][4];
+          sfor<0, kb>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const double* ujk = tile_at(j, kb);
+            const double* ujt = col_tile(j, tj);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { ua[j][g] = -ujk[nat + 64 * g]; ub[j][g] = ujt[nat + 64 * g]; }
+          });
+          sfor<0, kb>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) T[sl] = mma(ua[j][g], ub[j][g], T[sl]);
+          });
+        }
+      }
+      // LOOK-AHEAD: the next diagonal tile's left-looking sum over the block rows that are already final (j < kb), in place --
+      // wave 0 then only subtracts block row kb's term before it factors the tile (the chain of 4 kb dependent MFMAs in front of
+      // every diag_tile_inverse was on the sweep's critical path while three waves waited for M_kb)
+      if constexpr (kb >= 1 && kb + 1 < NB) {
+        if (wave == 1 + NITEM % 3) {
+          double* dt = tile_at(kb + 1, kb + 1);
+          v4d Dn;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Dn[g] = dt[nat + 64 * g];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (q + 4 * g == c && 16 * (kb + 1) + c >= p.r) Dn[g] = 1.0;
+          double ua[kb][4];
+          sfor<0, kb>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const double* ujk = tile_at(j, kb + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ua[j][g] = ujk[nat + 64 * g];
+          });
+          sfor<0, kb>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Dn = mma(-ua[j][g], ua[j][g], Dn);
+          });
+#pragma unroll
+          for (int g = 0; g < 4; ++g) dt[nat + 64 * g] = Dn[g];
+        }
+      }
     }
-#ifdef FINROM_SOLVE_CLOCKS
-    ck[6] += wall_clock64() - cd0;
-#endif
-    // M_kb, natural layout, for the backward sweep: Am[g] at lane (q, c) is M[c][q + 4 g]
+    __syncthreads();                                     // M_kb is in LDS
+    if (wave > 0) {
+      double Am[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) mbuf[kb * 256 + trn + 4 * g] = Am[g];
-#endif
-    // (b) U(kb, tj) = M T(kb, tj), Z_kb = M e
-    sfor<kb + 1, NB>([&](auto jc) {
-      constexpr int tj = decltype(jc)::value;
-      v4d n = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int g = 0; g < 4; ++g) Am[g] = mbuf[kb * 256 + trn + 4 * g];      // Am[g] at lane (q, c) = M[c][q + 4 g]
 #pragma unroll
-      for (int g = 0; g < 4; ++g) n = mma(Am[g], T[tj - kb][g], n);
-      double* ut = tile_at(kb, tj);
+      for (int sl = 0; sl < 2; ++sl) {
+        if (tjs[sl] < 0) continue;
+        v4d n = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) ut[nat + 64 * g] = n[g];
-    });
-    {
-      v4d n = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int g = 0; g < 4; ++g) n = mma(Am[g], T[sl][g], n);
+        double* ut = col_tile(kb, tjs[sl]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) n = mma(Am[g], e[g], n);
-      z[kb] = n;
+        for (int g = 0; g < 4; ++g) ut[nat + 64 * g] = n[g];
+      }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();                                     // block row kb of U and Z_kb are in LDS
+  });
+  if (wave > 0) return;
+  v4d z[NB];
+  sfor<0, NB>([&](auto kc) {
+    constexpr int kb = decltype(kc)::value;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) z[kb][g] = zl[kb * 256 + nat + 64 * g];
   });
 #ifdef FINROM_SOLVE_CLOCKS
   ck[3] = wall_clock64();

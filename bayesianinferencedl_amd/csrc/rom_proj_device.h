@@ -692,6 +692,9 @@ __device__ __forceinline__ void fused_solve_mw(const RomDev& p, d4 (&acc)[(NB * 
 // needs no backward substitution.  ~2.4 k vector instructions + 180 MFMAs per sample at r = 80.
 // ---------------------------------------------------------------------------------------
 constexpr int ROM_SW_LDS = 16 * 5;      // doubles of LDS per wave (B_r)
+#ifndef FINROM_SW_MFMA_DIAG_TILES
+#define FINROM_SW_MFMA_DIAG_TILES 6     // block rows with at most this many live tiles factor their diagonal tile on the matrix cores
+#endif
 template <int NB>
 __device__ __forceinline__ int fused_solve_sw(const RomDev& p, d4 (&acc)[NB * (NB + 1) / 2], const double (&bacc)[NB], int q, int c,
                                               double* __restrict__ mt, double& qout) {
@@ -742,7 +745,28 @@ __device__ __forceinline__ int fused_solve_sw(const RomDev& p, d4 (&acc)[NB * (N
     // M[c][4 g + q] -- so M needs no transposition through LDS (whose allocation would cost the band sweep, which shares the CU
     // and wants 37 KB per wave, a quarter of its waves)
     double Am[4];
-    {
+    // (the first block rows of a wide basis keep the shuffle steps: with 15 or 10 tiles live, diag_tile_inverse's working set does
+    //  not fit beside them under the kernel's 200-register cap -- hipcc spills, and spill code beside inline-asm MFMAs is not
+    //  hazard-safe; with <= 6 live tiles it does)
+#ifndef FINROM_SW_SHUFFLE_DIAG
+    constexpr bool kMfmaDiag = (NB - kb) * (NB - kb + 1) / 2 <= FINROM_SW_MFMA_DIAG_TILES;
+#else
+    constexpr bool kMfmaDiag = false;
+#endif
+    if constexpr (kMfmaDiag) {
+      // Round 4: the diagonal tile 4 x 4-blocked on the matrix cores (diag_tile_inverse, as the other two epilogues since round 3)
+      // instead of the 16 shuffle steps below.  It returns M in the C/D layout; the A operand of M T is M^T in that layout --
+      // and a tile in the C/D layout IS a valid A operand holding its own transpose (A[i = c][k = q] <- X[q + 4 g][c]), so
+      // M^T = sum_g X_g^T E_g with the identity's rows as B operands: FOUR MFMAs transpose the tile, no LDS (2 KB per wave here
+      // would cost the co-resident band sweep a quarter of its waves), no shuffles (16 of them spilled 140 registers).
+      d4 D = acc[tidx<NB>(kb, kb)];
+      const d4 Mc = diag_tile_inverse(D, q, c, q * 16 + c, bad);
+      d4 MT = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) MT = __builtin_amdgcn_mfma_f64_16x16x4f64(Mc[g], c == q + 4 * g ? 1.0 : 0.0, MT, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Am[g] = MT[g];
+    } else {
       d4& D = acc[tidx<NB>(kb, kb)];
 #pragma unroll
       for (int g = 0; g < 4; ++g) Am[g] = (q + 4 * g == c) ? 1.0 : 0.0;
@@ -801,7 +825,17 @@ __device__ __forceinline__ int fused_solve_sw(const RomDev& p, d4 (&acc)[NB * (N
           for (int tj = ti; tj < NB; ++tj)
             asm volatile("s_nop 3\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0 neg:[1,0,0]"
                          : "+v"(acc[tidx<NB>(ti, tj)]) : "v"((double)acc[tidx<NB>(kb, ti)][g]), "v"((double)acc[tidx<NB>(kb, tj)][g]));
-        mfma_drain(acc);
+        // (wait for the in-flight updates; only the tiles being updated are named -- naming all of acc would keep the finished
+        //  block rows' registers alive to the end of the epilogue)
+        bool first = true;
+#pragma unroll
+        for (int ti = kb + 1; ti < NB; ++ti)
+#pragma unroll
+          for (int tj = ti; tj < NB; ++tj) {
+            if (first) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(acc[tidx<NB>(ti, tj)]));
+            else asm volatile("" : "+v"(acc[tidx<NB>(ti, tj)]));
+            first = false;
+          }
       }
     }
   });

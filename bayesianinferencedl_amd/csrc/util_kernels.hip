@@ -1,5 +1,5 @@
 // Small helper kernels of the hot path: sub-fin averages, Gaussian-field sampler, difference.
-#include "finrom_internal.h"
+#include "finrom_core.h"
 #include <algorithm>
 
 namespace finrom {

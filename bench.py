@@ -51,10 +51,13 @@ def parse():
                     help="pairs: the FOM+ROM dataset loop (BASELINE metric, configs[1..3]); hmc: BASELINE configs[4], chains of "
                          "sequential dependent one-sample ROM + learned-error value-and-gradient calls (steps = calls per chain)")
     ap.add_argument("--chains", type=int, default=4, help="hmc: number of independent chains (sharded over the GPUs)")
-    ap.add_argument("--hmc-mode", default="device", choices=["device", "host"],
-                    help="hmc: 'device' keeps positions / momenta / gradients in HBM across a trajectory and replays one captured "
-                         "HIP graph per proposal (hmc.run_chains_device); 'host' is round 2's NumPy recursion around one library "
-                         "call per evaluation (three copies and a synchronisation each)")
+    ap.add_argument("--hmc-mode", default="device", choices=["device", "device-torch", "host"],
+                    help="hmc: 'device' keeps the chains in HBM and runs a whole proposal as library launches (finrom_hmc_begin / "
+                         "_leapfrog / _end: the position update in front of the contraction, the momentum update behind the "
+                         "gradient), one captured HIP graph per proposal (hmc.run_chains_fused); 'device-torch' is round 3's form: "
+                         "finrom_romml_grad between torch elementwise kernels in the same graph; 'host' is round 2's NumPy recursion "
+                         "around one library call per evaluation (three copies and a synchronisation each)")
+    ap.add_argument("--hmc-trace", action="store_true", help="hmc: keep and gather the per-proposal trace of every chain")
     ap.add_argument("--hmc-eps", type=float, default=None, help="hmc: leapfrog step size (default: tuned for 60-90 %% acceptance)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 run: nccl (= RCCL over xGMI, one rank per GPU) or gloo (host "
@@ -188,7 +191,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.dry_run:
-        return dry_run(args, rank, world)
+        return dry_run_hmc(args, rank, world) if args.workload == "hmc" else dry_run(args, rank, world)
     if args.workload == "hmc":
         return run_hmc(args, rank, local_rank, world)
     cpu_all = None
@@ -454,9 +457,10 @@ def run_hmc(args, rank, local_rank, world):
         sd = seeds if sd is None else sd
         if not mine:
             return None
-        if args.hmc_mode == "device":
-            return hmc.run_chains_device(solver_r, k0, n, seeds=sd, n_leapfrog=L, eps=eps)
-        return hmc.run_chains(f, k0, n, seeds=sd, n_leapfrog=L, eps=eps)
+        if args.hmc_mode != "host":
+            return hmc.run_chains_device(solver_r, k0, n, seeds=sd, n_leapfrog=L, eps=eps, fused=args.hmc_mode == "device",
+                                         keep_trace=args.hmc_trace)
+        return hmc.run_chains(f, k0, n, seeds=sd, n_leapfrog=L, eps=eps, keep_trace=args.hmc_trace)
     run(1 + max(L, args.warmup // L * L))
     fence()
     Lb = _ffi.lib()
@@ -466,11 +470,11 @@ def run_hmc(args, rank, local_rank, world):
     fence()
     dt = time.perf_counter() - t0
     Lb.finrom_profile_enable(0)
-    if args.hmc_mode == "device" and not args.no_profile and mine:
+    if args.hmc_mode != "host" and not args.no_profile and mine:
         # kernels replayed from a HIP graph cannot be bracketed with events: per-kernel times come from a short pass of the same
         # chains with the launches in stream order (not timed)
         Lb.finrom_profile_reset(); Lb.finrom_profile_enable(1)
-        hmc.run_chains_device(solver_r, K0, 1 + 20 * L, seeds=seeds, n_leapfrog=L, eps=eps, graph=False)
+        hmc.run_chains_device(solver_r, K0, 1 + 20 * L, seeds=seeds, n_leapfrog=L, eps=eps, graph=False, fused=args.hmc_mode == "device")
         torch.cuda.synchronize()
         Lb.finrom_profile_enable(0)
     prof = _ffi.profile_read()
@@ -479,6 +483,10 @@ def run_hmc(args, rank, local_rank, world):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    # the gather at the end ("cfg5: one chain per GPU, no communication until the final trace gather";
+    # bayesian_inference/inference.py:165-169 keeps the trace): end states, accept counts and -- with --hmc-trace -- the
+    # per-proposal traces of every rank's chains, assembled on rank 0 in chain order
+    chains = gather_chains(res, mine, world, dist if world > 1 else None)
     # one chain alone, one sample per call: the per-call latency a single PyMC chain would see (not timed above)
     lat = None
     if rank == 0 and mine:
@@ -493,25 +501,18 @@ def run_hmc(args, rank, local_rank, world):
         total = args.chains * n_evals
         ms = {k: (v[1] / v[0] if v[0] else 0.0) for k, v in prof.items()}
         dom = max(prof, key=lambda k: prof[k][1]) if any(v[1] for v in prof.values()) else None
-        roof = None
-        pairs_n_obs = len(solver_r.data)
-        if dom == "rom_proj_mfma" and ms[dom] > 0 and args.projection == "direct":
-            ops = V.operators()
-            alg = len(mine) * (ops.n * r * (r + 1) + 2 * solver_r._rom.nterms * r + r ** 3 // 3)
-            ach = alg / (ms[dom] * 1e-3) / 1e12
-            roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None, "avg_launch_ms": ms[dom],
-                    "note": "latency-bound workload: one wave per chain runs the whole contraction; the fraction is what one call leaves of the chip, not a kernel-quality figure"}
-        elif dom == "rom_reduced_solve" and ms[dom] > 0:
-            # substitutions + adjoint + gradient contraction on the stored factor: what has to move per call is the packed factor
-            # (read by both solves) and the vectors; one wave per chain, so this, too, is a latency figure
-            rp = (r + 15) // 16 * 16
-            alg = len(mine) * 8 * (2 * (rp * (rp + 1) // 2) + 4 * rp + pairs_n_obs + 9)
-            ach = alg / (ms[dom] * 1e-3) / 1e9
-            roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
-                    "traffic": None, "avg_launch_ms": ms[dom],
-                    "note": "latency-bound workload: the one-sample solve kernel (one wave per chain factors and substitutes in MFMA form, "
-                            "tiles in LDS) + the gradient contraction; lower-bound bytes of the old packed-factor model, kept as an order of magnitude"}
+        roof = None                                       # (no throughput roofline for a latency chain: see critical_path)
+        # a chain of DEPENDENT one-sample calls has no throughput roofline: what bounds it is the critical path of a leapfrog step --
+        # the step's launches in order, each waiting for the previous one (durations from the stream-order pass above)
+        lib_order = ["rom_proj_mfma", "rom_reduced_solve", "misc"]
+        crit = {k: round(ms[k] * 1e3 * (prof[k][0] / max(prof["rom_proj_mfma"][0], 1)), 2) for k in lib_order if ms.get(k, 0) > 0} if prof.get("rom_proj_mfma", (0, 0))[0] else None
+        critical_path = None if not crit else {
+            "bound": "latency", "per_step_us": crit, "sum_us": round(sum(crit.values()), 2),
+            "measured_step_us": round(1e6 * dt / n_evals, 2),
+            "note": "one leapfrog step = dependent launches: contraction + theta + error-model forward (rom_proj_mfma), factor + "
+                    "forward / adjoint solves and the gradient contraction (rom_reduced_solve: two launches), error-model backward + "
+                    "momentum update (misc: also the proposal's begin / end kernels); kernel durations from a stream-order pass, "
+                    "the measured step adds the graph's per-node launch gaps"}
         cpu = None
         if world == 1 and args.cpu_samples > 0:
             cpu = hmc_cpu_baseline(args, phi, model, solver_r.data, K0, res)
@@ -524,11 +525,72 @@ def run_hmc(args, rank, local_rank, world):
                                    f"(n={V.dim()}), r={r}, res_bn_fc error model 5 x 50, {L} leapfrog steps per proposal, "
                                    f"{len(mine)} chains per call on rank 0", "chains": args.chains, "evals_per_chain": n_evals,
                        "r": r, "projection": args.projection, "accepted": res["accept"].tolist() if res else None,
+                       "accepted_all_chains": chains["accept"],
                        "proposals": res["proposals"] if res else None, "eps": eps, "mode": args.hmc_mode,
+                       "fused_leapfrog": bool(res.get("fused")) if res else None,
                        "hip_graph": bool(res.get("graph")) if res else None,
                        "acceptance": float(np.mean(res["accept"]) / max(res["proposals"], 1)) if res else None},
-            "roofline": roof, "cpu_baseline": cpu, "single_chain_latency_ms_per_call": None if lat is None else 1e3 * lat,
+            "roofline": roof, "critical_path": critical_path, "cpu_baseline": cpu,
+            "chains_sha256": chains["sha256"], "chains_gathered": chains["n"], "trace_sha256": chains["trace_sha256"],
+            "single_chain_latency_ms_per_call": None if lat is None else 1e3 * lat,
             "kernels_avg_ms": {k: round(v, 4) for k, v in ms.items() if v > 0}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def gather_chains(res, mine, world, dist):
+    """End states [chains x n], accept counts and optional traces of every rank's chains on rank 0, in chain order, + checksums.
+    The payload is small (a few fields per chain), so it travels as Python objects (gather_object: gloo or RCCL alike)."""
+    import hashlib
+    part = {c: (res["K"][i], int(res["accept"][i]), None if res.get("trace") is None else res["trace"][:, i]) for i, c in enumerate(mine)} if res else {}
+    parts = [part]
+    if dist is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+    allc = {}
+    for p_ in parts:
+        allc.update(p_)
+    order = sorted(allc)
+    h = hashlib.sha256()
+    for c in order:
+        h.update(np.ascontiguousarray(allc[c][0]).tobytes()); h.update(np.int64(allc[c][1]).tobytes())
+    ht = None
+    if order and allc[order[0]][2] is not None:
+        ht = hashlib.sha256()
+        for c in order:
+            ht.update(np.ascontiguousarray(allc[c][2]).tobytes())
+        ht = ht.hexdigest()
+    return {"n": len(order), "sha256": h.hexdigest(), "accept": [allc[c][1] for c in order], "trace_sha256": ht}
+
+
+def dry_run_hmc(args, rank, world):
+    """No GPU: the chain deal (rank g owns chains g, g + N, ...), a stand-in for the chains (a deterministic walk seeded per chain)
+    and the gather of end states / accept counts / traces over gloo; rank 0 checks the assembled result against the one-process
+    one and prints the JSON line with value = null."""
+    import torch.distributed as dist
+    n, L = 64, 10
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+
+    def walk(chain_ids):
+        K = np.stack([np.cumsum(np.random.default_rng(1000 + c).standard_normal((args.steps // L + 1, n)), axis=0) for c in chain_ids], axis=1) \
+            if chain_ids else np.zeros((args.steps // L + 1, 0, n))
+        return {"K": K[-1], "accept": np.array([int(abs(K[-1, i]).sum()) % 7 for i in range(len(chain_ids))]), "trace": K}
+    mine = [c for c in range(args.chains) if c % world == rank]
+    t0 = time.perf_counter()
+    got = gather_chains(walk(mine), mine, world, dist if world > 1 else None)
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        every = list(range(args.chains))
+        ref = gather_chains(walk(every), every, 1, None)
+        assert got == ref, "gathered chains differ from the one-process run"
+        print(json.dumps({"metric": "ROM+DL value-and-gradient evaluations/sec (HMC chains, BASELINE configs[4])", "value": None,
+                          "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": "dry run: chain deal + gloo gather of end states / accept counts / traces only",
+                                     "chains": args.chains}, "dry_run": True, "gather_s": dt, "chains_gathered": got["n"],
+                          "chains_sha256": got["sha256"], "trace_sha256": got["trace_sha256"]}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 10
+#define FINROM_ABI_VERSION 11
 
 typedef enum {
   FINROM_OK = 0,
@@ -373,6 +373,39 @@ int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, vo
 int finrom_romml_grad(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
                       int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
                       int32_t* info, void* stream);
+
+/* ---- HMC trajectories on the device (BASELINE configs[4]) ----------------------------------------------------------------------- *
+ * PyMC3's sampler calls the reference's value-and-gradient op once per leapfrog step (bayesian_inference/pymc_func_bayes_inverse.py:
+ * 92-104 `err_grad_ROMML`, :148-167 `SqErrorOpROMML.perform`; model :186-203: potential = misfit / sigma^2 on a latent Gaussian
+ * field) and does the trajectory's arithmetic itself, on the host.  Here a whole proposal is library launches on device-resident
+ * chain state, so that it can be captured once in a HIP graph and replayed (bayesianinferencedl_amd/bayesian_inference/hmc.py):
+ *   finrom_hmc_begin     momentum of proposal *jt of the uploaded block, H0 = U + |p|^2 / 2, Kq[0] = K, first half step of p;
+ *   finrom_hmc_leapfrog  ONE leapfrog step in the four launches of finrom_romml_grad: the position update k <- k + eps p rides in
+ *                        front (every kernel that reads the field forms it; Kq[step & 1] -> Kq[(step + 1) & 1]), the value and
+ *                        gradient of the ROM + learned-error misfit at the new point are finrom_romml_grad's, and the momentum
+ *                        update p <- p - eps c_pri dU, dU = (k - mean) + (c_lik / c_pri) grad (0 for a flagged sample), rides
+ *                        behind the gradient; loss [C] and info [C] of the state are overwritten; grad_out [C x n] optional;
+ *   finrom_hmc_end       after n_steps steps: last half step back, U(k) = c_lik loss + c_pri |k - mean|^2 / 2 (inf if flagged),
+ *                        Metropolis test log u < H0 - H1, state update, accept counters, optional trace row, *jt += 1, *pt += 1.
+ * Potential: i.i.d. Gaussian prior N(mean, 1 / c_pri) per node, likelihood scale c_lik = 1 / sigma^2.  All arrays are DEVICE
+ * pointers owned by the caller; C <= 64 chains advance in lockstep (one sample of the batch each); needs finrom_rom_set_gradient,
+ * the direct projection, P <= 16 and a basis the one-sample pipeline serves (r <= 96) -- FINROM_ERR_UNSUPPORTED otherwise. */
+typedef struct {
+  int64_t C; int32_t n;                 /* chains, nodes of the field */
+  double eps, c_lik, c_pri;             /* leapfrog step, 1 / sigma^2, 1 / tau^2 */
+  const double* mean;                   /* [C x n] */
+  double* K; double* U; double* dU;     /* chain state: position [C x n], potential [C], grad U / c_pri [C x n] */
+  double* Kq[2]; double* P; double* dUq; double* H0;   /* trajectory: positions (ping-pong) [C x n] x 2, momentum, grad U / c_pri, H0 [C] */
+  const double* P_block; const double* lu_block;       /* draws of a block of B proposals: momenta [B x C x n], log-uniforms [B x C] */
+  int64_t* jt; int64_t* pt;             /* device counters: proposal inside the block, proposal of the chain (trace row - 1) */
+  int64_t* accept;                      /* [C] accepted proposals */
+  double* trace;                        /* [(proposals + 1) x C x n] or NULL */
+  double* loss; int32_t* info;          /* [C] value and flags of the last evaluation */
+} finrom_hmc_state;
+int finrom_hmc_begin(const finrom_hmc_state* st, void* stream);
+int finrom_hmc_leapfrog(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const finrom_hmc_state* st, int32_t step,
+                        const double* data, int32_t data_per_sample, double* grad_out, double* qoi_r, double* e_nn, void* stream);
+int finrom_hmc_end(const finrom_hmc_state* st, int32_t n_steps, void* stream);
 
 /* ---- sub-fin averages  theta = S k  (fom :466-480, rom :404-418) -------------------- *
  * Sop is the dense [P x n] averaging operator on the device (finrom_malloc + h2d). */

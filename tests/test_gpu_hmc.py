@@ -60,8 +60,9 @@ def test_hmc_chains_value_and_gradient_match_the_oracle(setup, projection):
     assert np.linalg.norm(solo.K[0] - lock.K[1]) <= 1e-6 * np.linalg.norm(lock.K[1])
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("graph", [True, False])
-def test_device_resident_chains_walk_the_host_chains_path(setup, graph):
+def test_device_resident_chains_walk_the_host_chains_path(setup, graph, fused):
     """hmc.run_chains_device -- positions, momenta, gradients, the Metropolis test and the accept counters stay on the device, one
     captured HIP graph per PROPOSAL (graph=True) or the same launches in stream order -- must walk the path of the host recursion
     with the same seeds (the elementwise updates round differently: 1e-9), accept the same proposals, and its recorded
@@ -77,7 +78,10 @@ def test_device_resident_chains_walk_the_host_chains_path(setup, graph):
     kw = dict(seeds=[100 + c for c in chains], eps=3e-2, n_leapfrog=10)
     want = {0, 1, 10, 55, 120}
     host = hmc.run_chains(hmc.romml_value_and_grad(rom), K0, 121, record=want, **kw)
-    dev = hmc.run_chains_device(rom, K0, 121, record=want, graph=graph, **kw)
+    # fused: the trajectory's arithmetic inside the library (finrom_hmc_begin / _leapfrog / _end, round 4); not fused: round 3's
+    # form, finrom_romml_grad between torch elementwise kernels
+    dev = hmc.run_chains_device(rom, K0, 121, record=want, graph=graph, fused=fused, **kw)
+    assert dev.fused == fused
     assert dev.graph == graph, "HIP graph capture of the leapfrog step failed" if graph else "graph not requested"
     assert dev.n_evals == host.n_evals == 121 and dev.proposals == host.proposals == 12
     assert 0 < host.accept.sum() < 4 * 12, host.accept           # some accepted, some rejected
@@ -91,8 +95,9 @@ def test_device_resident_chains_walk_the_host_chains_path(setup, graph):
         assert abs(loss[2] - lo) <= 2e-5 * abs(lo) and np.linalg.norm(grad[2] - go) <= 1e-5 * np.linalg.norm(go), ev
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("graph,block", [(True, 32), (True, 5), (False, 7)])
-def test_device_chains_without_host_round_trips_reproduce_the_host_chains(setup, graph, block):
+def test_device_chains_without_host_round_trips_reproduce_the_host_chains(setup, graph, block, fused):
     """Nothing recorded: every proposal is one graph replay (or the same kernels in stream order) and the host sees the chain
     only at its end.  Random numbers drawn `block` proposals ahead and uploaded block by block (block = 5: blocks of 5, 5, 4;
     the device-side slice counter restarts per block): same accepted proposals, same end points, same per-proposal trace as the
@@ -105,8 +110,8 @@ def test_device_chains_without_host_round_trips_reproduce_the_host_chains(setup,
     K0 = np.stack([np.exp(0.1 * np.random.default_rng(6 + c).standard_normal(V.dim())) for c in chains])
     kw = dict(seeds=[100 + c for c in chains], eps=3e-2, n_leapfrog=10, keep_trace=True)
     host = hmc.run_chains(hmc.romml_value_and_grad(rom), K0, 141, **kw)
-    dev = hmc.run_chains_device(rom, K0, 141, graph=graph, block=block, **kw)
-    assert dev.graph == graph and dev.n_evals == host.n_evals == 141 and dev.proposals == host.proposals == 14
+    dev = hmc.run_chains_device(rom, K0, 141, graph=graph, block=block, fused=fused, **kw)
+    assert dev.fused == fused and dev.graph == graph and dev.n_evals == host.n_evals == 141 and dev.proposals == host.proposals == 14
     assert 0 < host.accept.sum() < 4 * 14, host.accept
     assert np.array_equal(dev.accept, host.accept)
     assert dev.trace.shape == host.trace.shape == (15, 4, V.dim())
@@ -124,4 +129,6 @@ def test_bench_hmc_mode_contract():
     assert d["unit"] == "evals/s" and d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["chains"] == 4
     assert d["config"]["evals_per_chain"] == 41 and d["config"]["r"] == 81
     assert d["single_chain_latency_ms_per_call"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["roofline"] is None and d["critical_path"]["bound"] == "latency" and d["critical_path"]["sum_us"] > 0
+    assert d["config"]["fused_leapfrog"] is True and d["config"]["hip_graph"] is True and d["chains_gathered"] == 4 and len(d["chains_sha256"]) == 64
     assert abs(d["value"] - 4 * 41 / (d["ms_per_step"] * 41e-3)) < 1e-6 * d["value"]

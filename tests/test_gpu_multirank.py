@@ -33,6 +33,22 @@ def test_two_ranks_reproduce_the_single_process_outputs(params, extra):
     assert two["value"] > 0 and two["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("mode", ["device", "device-torch"])
+def test_hmc_chains_sharded_over_two_ranks_walk_the_single_process_paths(mode):
+    """configs[4] ("4 chains ... sharded one chain/GPU") with two ranks sharing cuda:0 over gloo: rank g owns chains g, g + 2; every
+    chain must end where it ends in the one-process run (4 chains in lockstep) -- a chain's sums do not depend on which chains share
+    its launches -- with the same accept counts and the same per-proposal trace: the gathered checksums are equal."""
+    common = ["--workload", "hmc", "--chains", "4", "--steps", "60", "--warmup", "10", "--cpu-samples", "0", "--no-profile",
+              "--hmc-trace", "--hmc-mode", mode, "--hmc-eps", "0.03"]
+    two = _bench(["--gpus", "2", "--backend", "gloo"] + common)
+    one = _bench(["--gpus", "1"] + common)
+    assert two["n_gpus"] == 2 and two["chains_gathered"] == one["chains_gathered"] == 4
+    assert two["config"]["fused_leapfrog"] == (mode == "device") and two["config"]["hip_graph"] is True
+    assert sum(one["config"]["accepted_all_chains"]) > 0
+    assert two["config"]["accepted_all_chains"] == one["config"]["accepted_all_chains"]
+    assert two["chains_sha256"] == one["chains_sha256"] and two["trace_sha256"] == one["trace_sha256"] is not None
+
+
 def test_one_rank_rccl_process_group_and_device_gather():
     """The `nccl` backend (= RCCL on ROCm) executed for real before the first multi-GPU run: one rank started by
     torch.distributed.run (launched before anything touches the GPU), --force-pg creates the RCCL communicator with

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in finrom.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib.finrom_version.restype = ctypes.c_int
-    assert lib.finrom_version() == _ffi.ABI_VERSION == 10
+    assert lib.finrom_version() == _ffi.ABI_VERSION == 11
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -177,6 +177,17 @@ def test_bench_gpus2_launches_two_ranks_and_matches_single_process():
     assert two["gathered_sha256"] == one["gathered_sha256"]
     nine = _bench_json(["--gpus", "2", "--dry-run", "--samples", "1000", "--params", "field"])
     assert nine["n_gpus"] == 2
+
+
+def test_bench_hmc_chain_deal_and_gather_over_two_ranks():
+    """configs[4]'s multi-rank form on CPU (`--workload hmc --gpus 2 --dry-run`): chains dealt round robin (rank g owns g, g + N, ...),
+    end states / accept counts / traces gathered on rank 0 in chain order; the checksums must equal the one-process run's, also when
+    the chains do not divide by the ranks (4 chains on 3 ranks).  tests/test_gpu_multirank.py runs the real chains the same way."""
+    one = _bench_json(["--workload", "hmc", "--gpus", "1", "--dry-run", "--steps", "40", "--chains", "4"])
+    for n in (2, 3):
+        got = _bench_json(["--workload", "hmc", "--gpus", str(n), "--dry-run", "--steps", "40", "--chains", "4"])
+        assert got["n_gpus"] == n and got["chains_gathered"] == 4 and got["dry_run"] is True
+        assert got["chains_sha256"] == one["chains_sha256"] and got["trace_sha256"] == one["trace_sha256"] is not None
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
