@@ -357,9 +357,9 @@ int launch_sampler(const double* U, int n, const double* xi, int64_t S, double* 
     return 0;
   }
   const bool no_pad = getenv("FINROM_SAMPLER_NO_PAD") != nullptr;            // (experiment: every tile stops at its own K end)
-  const char* env_wm = getenv("FINROM_SAMPLER_WM");                          // (A/B: 4 = 256-row tiles, one workgroup per CU)
-  if (env_wm && atoi(env_wm) == 4) return launch_sampler_gemm<4>(U, n, xi, S, k, st, !no_pad);
-  return launch_sampler_gemm<2>(U, n, xi, S, k, st, !no_pad);
+  const char* env_wm = getenv("FINROM_SAMPLER_WM");                          // (A/B: 2 = 128-row tiles, two workgroups per CU)
+  if (env_wm && atoi(env_wm) == 2) return launch_sampler_gemm<2>(U, n, xi, S, k, st, !no_pad);
+  return launch_sampler_gemm<4>(U, n, xi, S, k, st, !no_pad);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -32,11 +32,14 @@ def test_throughput_sampler_kernel_matches_numpy_and_the_small_kernel_bit_for_bi
     monkeypatch.setenv("FINROM_SAMPLER_NO_PAD", "1")              # every tile stops at its own K end: the padding adds exact zeros
     nopad = smp(xt).cpu().numpy()
     monkeypatch.delenv("FINROM_SAMPLER_NO_PAD")
+    monkeypatch.setenv("FINROM_SAMPLER_WM", "2")                  # the 128 x 128 instantiation (two workgroups per CU; A/B only)
+    half = smp(xt).cpu().numpy()
+    monkeypatch.delenv("FINROM_SAMPLER_WM")
     monkeypatch.setenv("FINROM_SAMPLER_GEMM_MIN", str(1 << 40))   # the 64 x 64 kernel
     small = smp(xt).cpu().numpy()
     ref = np.exp(0.5 * (xi @ U))
     assert np.max(np.abs(big - ref) / ref) < 1e-13
-    assert np.array_equal(big, small) and np.array_equal(big, nopad)
+    assert np.array_equal(big, small) and np.array_equal(big, nopad) and np.array_equal(big, half)
 
 
 def test_sampler_dispatches_by_batch_size_and_seeded_draws_do_not_depend_on_it():

@@ -24,10 +24,10 @@ only = sys.argv[3] if len(sys.argv) > 3 else None
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 res = {}
 for tag, env in (("small_64x64", {"FINROM_SAMPLER_GEMM_MIN": str(1 << 40)}),
-                 ("gemm_256x128", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_WM": "4"}),
-                 ("gemm_256x128_nopad", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_NO_PAD": "1", "FINROM_SAMPLER_WM": "4"}),
-                 ("gemm_128x128", {"FINROM_SAMPLER_GEMM_MIN": "1"}),
-                 ("gemm_128x128_nopad", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_NO_PAD": "1"})):
+                 ("gemm_256x128", {"FINROM_SAMPLER_GEMM_MIN": "1"}),
+                 ("gemm_256x128_nopad", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_NO_PAD": "1"}),
+                 ("gemm_128x128", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_WM": "2"}),
+                 ("gemm_128x128_nopad", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_NO_PAD": "1", "FINROM_SAMPLER_WM": "2"})):
     if only and tag != only:
         continue
     for k in ("FINROM_SAMPLER_GEMM_MIN", "FINROM_SAMPLER_NO_PAD", "FINROM_SAMPLER_WM"):
