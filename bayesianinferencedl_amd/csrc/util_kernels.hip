@@ -1,6 +1,7 @@
 // Small helper kernels of the hot path: sub-fin averages, Gaussian-field sampler, difference.
 #include "finrom_core.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace finrom {
 
@@ -161,10 +162,14 @@ constexpr int SG_TS = 80;                         // doubles between two operand
 // per-chunk barrier and LDS hand-over are covered by the other's MFMAs.
 template <int WM> struct SGeo {
   static constexpr int TM = 64 * WM, THREADS = 128 * WM;
-  static constexpr int A_BUF = 4 * (4 * WM) * SG_TS;        // [k-step][row tile] per buffer
+  // doubles per k-step block of A: its row tiles + 64 B, so that the four k-steps a staging instruction writes together (4 lanes
+  // per row: coalesced 128-B row reads) land on four different 16-bank groups -- without it every A write was a 4-way bank conflict
+  // and the burst of them held up the operand reads (WM = 2 has no room for it beside a second workgroup)
+  static constexpr int A_KS = 4 * WM * SG_TS + (WM == 4 ? 8 : 0);
+  static constexpr int A_BUF = 4 * A_KS;                    // [k-step][row tile] per buffer
   static constexpr int B_BUF = 4 * 8 * SG_TS;               // [k-step][col tile]
   static constexpr size_t LDS_BYTES = (size_t)2 * (A_BUF + B_BUF) * sizeof(double);
-  static constexpr int B_ITEMS = 512 / THREADS;             // 4-column items of the U chunk per thread
+  static constexpr int B_ITEMS = 1024 / THREADS;            // 2-column items (one 16-byte load / LDS write each) of the U chunk per thread
   static constexpr int SM_PER_SUPER = 1024 / TM;            // sample tiles of a super-tile (1024 samples x 8 column tiles per XCD)
 };
 constexpr int64_t SAMPLER_GEMM_MIN_S = 4096;      // below: the 64 x 64 kernel fills the chip better
@@ -173,7 +178,7 @@ constexpr int64_t SAMPLER_GEMM_MIN_S = 4096;      // below: the 64 x 64 kernel f
 
 template <int WM, int NT>      // NT = this wave's live column tiles (4; fewer only in the last column tile of a factor whose n is not a multiple of 128)
 __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n, const double* __restrict__ xi, int64_t S,
-                                             double* __restrict__ kout, int64_t s0, int j0, int nch, double* lds) {
+                                             double* __restrict__ kout, int64_t s0, int j0, int nch, double* lds, int xflags) {
   typedef SGeo<WM> G;
   constexpr int SG_A_BUF = G::A_BUF, SG_B_BUF = G::B_BUF;
   double* Abuf = lds;
@@ -182,7 +187,9 @@ __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n
   const int q = lane >> 4, c = lane & 15;
   // staging: A = two items of 4 consecutive k for one row (4 lanes cover a row's 128 B), B = one item of 4 consecutive columns
   const int a_row = tid >> 2, a_kq = tid & 3;
-  const int b_k = tid >> 5, b_j = (tid & 31) * 4;            // (+ THREADS / 32 rows per further item)
+  // (a wave's 64 lanes take 128 consecutive columns of ONE row of U: 1 KB contiguous from memory, and in LDS eight lanes fill a
+  //  column tile's 128-B row while the next eight land 640 B = 32 banks further: conflict-free 16-byte writes)
+  const int b_k = tid >> 6, b_j = (tid & 63) * 2;            // (+ THREADS / 64 rows per further item)
   // Operand fetches are BUFFER loads (two 16-byte loads per item): rows beyond the batch / beyond the factor fall outside the
   // resource and come back as zeros without a branch; the chunk offset rides in an SGPR.  (k >= n inside a row reads the head of
   // the next row -- selected away below; columns j >= n of U read the next row of U and only feed output columns that are never
@@ -194,41 +201,47 @@ __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n
   const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(U + j0), 0, (int)(((int64_t)n * n - j0) * 8), 0x00020000);
   const int a_voff0 = (a_row * n + 4 * a_kq) * 8, a_voff1 = ((a_row + G::TM / 2) * n + 4 * a_kq) * 8;
   const int b_voff = (b_k * n + b_j) * 8;
-  double ra[2][4], rb[G::B_ITEMS][4];
-  auto gload = [&](int ch) {
+  double ra[2][2][4], rb[2][G::B_ITEMS][2];              // two chunks in flight (register sets 0 / 1)
+  auto gload = [&](int ch, auto setc) {
+    constexpr int st = decltype(setc)::value;
     const int k0 = ch * 16;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int vo = it ? a_voff1 : a_voff0;
       const d2_t lo = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(ares, vo, k0 * 8, 0));
       const d2_t hi = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(ares, vo + 16, k0 * 8, 0));
-      ra[it][0] = lo[0]; ra[it][1] = lo[1]; ra[it][2] = hi[0]; ra[it][3] = hi[1];
+      ra[st][it][0] = lo[0]; ra[st][it][1] = lo[1]; ra[st][it][2] = hi[0]; ra[st][it][3] = hi[1];
     }
 #pragma unroll
     for (int it = 0; it < G::B_ITEMS; ++it) {
-      const int so = (k0 + it * (G::THREADS / 32)) * n * 8;
+      const int so = (k0 + it * (G::THREADS / 64)) * n * 8;
       const d2_t lo = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(bres, b_voff, so, 0));
-      const d2_t hi = __builtin_bit_cast(d2_t, __builtin_amdgcn_raw_buffer_load_b128(bres, b_voff + 16, so, 0));
-      rb[it][0] = lo[0]; rb[it][1] = lo[1]; rb[it][2] = hi[0]; rb[it][3] = hi[1];
+      rb[st][it][0] = lo[0]; rb[st][it][1] = lo[1];
     }
   };
-  auto lwrite = [&](int buf, int ch) {                                // (ch: the chunk the staging registers hold)
+  auto lwrite = [&](int buf, int ch, auto setc) {                     // (ch: the chunk register set `setc` holds)
+    constexpr int st = decltype(setc)::value;
     const int kk = ch * 16 + 4 * a_kq;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int row = a_row + (G::TM / 2) * it;
-      double* dst = Abuf + buf * SG_A_BUF + (a_kq * (4 * WM) + (row >> 4)) * SG_TS + (row & 15);
-      // (k >= n: the load wrapped into the next row -- zero it HERE, not where the load was issued: a select there would wait for
-      //  the load it should let fly for a whole chunk)
+      double* dst = Abuf + buf * SG_A_BUF + a_kq * G::A_KS + (row >> 4) * SG_TS + (row & 15);
+      // (k >= n, the factor's last chunk only: the load wrapped into the next row -- zero it HERE, not where the load was issued: a
+      //  select there would wait for the load it should let fly for a whole chunk; and only in that chunk: 16 selects per chunk were
+      //  a tenth of the kernel -- every vector instruction costs the matrix pipe ~11 cycles)
+      if (ch * 16 + 16 > n) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dst[e * 16] = kk + e < n ? ra[it][e] : 0.0;            // e = q: the k inside the k-step
+        for (int e = 0; e < 4; ++e) dst[e * 16] = kk + e < n ? ra[st][it][e] : 0.0;      // e = q: the k inside the k-step
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e * 16] = ra[st][it][e];
+      }
     }
 #pragma unroll
     for (int it = 0; it < G::B_ITEMS; ++it) {
-      const int bk = b_k + it * (G::THREADS / 32);
+      const int bk = b_k + it * (G::THREADS / 64);
       double* dstb = Bbuf + buf * SG_B_BUF + ((bk >> 2) * 8 + (b_j >> 4)) * SG_TS + (bk & 3) * 16 + (b_j & 15);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dstb[e] = rb[it][e];
+      dstb[0] = rb[st][it][0]; dstb[1] = rb[st][it][1];
     }
   };
   auto exchange = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
@@ -241,12 +254,17 @@ __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n
   const double* Ard = Abuf + (4 * wm) * SG_TS + lane;
   const double* Brd = Bbuf + (4 * wn) * SG_TS + lane;
 
-  gload(0);
-  lwrite(0, 0);
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  gload(0, S0{});
+  lwrite(0, 0, S0{});
   exchange();
-  if (nch > 1) gload(1);
-  for (int ch = 0; ch < nch; ++ch) {
-    const int cur = ch & 1;
+  if (nch > 1) gload(1, S1{});                           // chunk c lives in register set c & 1 ...
+  if (nch > 2) gload(2, S0{});                           // ... and TWO chunks are in flight: one chunk of MFMAs (1.7-3.4 us) did not
+                                                         //     cover the fetch's latency under load
+  // (two chunks per trip, the buffer a compile-time constant: every LDS address of the loop is base + immediate)
+  auto chunk = [&](auto curc, int ch) {
+    constexpr int cur = decltype(curc)::value;
     const double* Ac = Ard + cur * SG_A_BUF;
     const double* Bc = Brd + cur * SG_B_BUF;
     double av[2][4], bv[2][NT > 0 ? NT : 1];
@@ -261,7 +279,7 @@ __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n
       if constexpr (NT > 0) {
         if (ks < 3) {                                    // the next k-step's operands are on their way while this one's MFMAs issue
 #pragma unroll
-          for (int i = 0; i < 4; ++i) av[(ks + 1) & 1][i] = Ac[((ks + 1) * (4 * WM) + i) * SG_TS];
+          for (int i = 0; i < 4; ++i) av[(ks + 1) & 1][i] = Ac[(ks + 1) * G::A_KS + i * SG_TS];
 #pragma unroll
           for (int t = 0; t < NT; ++t) bv[(ks + 1) & 1][t] = Bc[((ks + 1) * 8 + t) * SG_TS];
         }
@@ -270,13 +288,19 @@ __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n
 #pragma unroll
           for (int t = 0; t < NT; ++t) SG_MFMA(acc[i][t], av[ks & 1][i], bv[ks & 1][t]);
       }
-      if (ks == 1 && ch + 1 < nch) {                     // chunk ch + 1 (requested an iteration ago) goes to the other buffer ...
-        lwrite(cur ^ 1, ch + 1);
-        if (ch + 2 < nch) gload(ch + 2);                 // ... and chunk ch + 2 is requested: a whole chunk of MFMAs to arrive in
+      if (ks == 1 && ch + 1 < nch && !(xflags & 2)) {    // chunk ch + 1 (requested an iteration ago) goes to the other buffer ...
+        lwrite(cur ^ 1, ch + 1, std::integral_constant<int, cur ^ 1>{});
+        if (ch + 3 < nch) gload(ch + 3, std::integral_constant<int, cur ^ 1>{});      // ... and its register set takes chunk ch + 3
       }
     }
-    exchange();
+    if (!(xflags & 1)) exchange();                       // (xflags: timing experiments, results are garbage -- FINROM_SAMPLER_XFLAGS)
+  };
+  int ch = 0;
+  for (; ch + 1 < nch; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    chunk(std::integral_constant<int, 1>{}, ch + 1);
   }
+  if (ch < nch) chunk(std::integral_constant<int, 0>{}, ch);
   if constexpr (NT > 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -301,7 +325,7 @@ __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n
 template <int WM>
 __global__ __launch_bounds__(128 * WM) void sampler_gemm_kernel(const double* __restrict__ U, int n, const double* __restrict__ xi,
                                                               int64_t S, double* __restrict__ kout, int n_sgroups, int n_cgroups,
-                                                              int top_tile, int pad_k) {
+                                                              int top_tile, int pad_k, int xflags) {
   extern __shared__ __attribute__((aligned(16))) double sg_lds[];
   typedef SGeo<WM> G;
   constexpr int WGS = 8 * G::SM_PER_SUPER;               // workgroups of a super-tile = what one XCD runs together (32 CUs)
@@ -318,14 +342,16 @@ __global__ __launch_bounds__(128 * WM) void sampler_gemm_kernel(const double* __
   const int64_t s0 = ((int64_t)sgp * G::SM_PER_SUPER + sm) * G::TM;
   if (s0 >= S) return;
   const int j0 = jt * 128;
-  const int kend = min(n, ((pad_k ? top : jt) + 1) * 128);
+  // lockstep (the whole super-tile to the top tile's K end) where the padding is cheap: column groups whose K end is >= 2048 -- below,
+  // the 3.5 tiles of average padding are 20-40 % of the group's work and its strips are short anyway (6.81 -> 6.70 ms, +0.1 GB)
+  const int kend = min(n, ((cg < pad_k && (top + 1) * 128 >= 2048 ? top : jt) + 1) * 128);
   const int nch = (kend + 15) / 16;
   const int live = (n - j0 - 64 * ((int)(threadIdx.x >> 6) & 1) + 15) / 16;     // this wave's column tiles that hold columns < n
-  if (live >= 4) sampler_tile<WM, 4>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
-  else if (live == 3) sampler_tile<WM, 3>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
-  else if (live == 2) sampler_tile<WM, 2>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
-  else if (live == 1) sampler_tile<WM, 1>(U, n, xi, S, kout, s0, j0, nch, sg_lds);
-  else sampler_tile<WM, 0>(U, n, xi, S, kout, s0, j0, nch, sg_lds);               // (stages and meets the barriers, no MFMAs)
+  if (live >= 4) sampler_tile<WM, 4>(U, n, xi, S, kout, s0, j0, nch, sg_lds, xflags);
+  else if (live == 3) sampler_tile<WM, 3>(U, n, xi, S, kout, s0, j0, nch, sg_lds, xflags);
+  else if (live == 2) sampler_tile<WM, 2>(U, n, xi, S, kout, s0, j0, nch, sg_lds, xflags);
+  else if (live == 1) sampler_tile<WM, 1>(U, n, xi, S, kout, s0, j0, nch, sg_lds, xflags);
+  else sampler_tile<WM, 0>(U, n, xi, S, kout, s0, j0, nch, sg_lds, xflags);               // (stages and meets the barriers, no MFMAs)
 }
 
 template <int WM>
@@ -340,7 +366,8 @@ static int launch_sampler_gemm(const double* U, int n, const double* xi, int64_t
   if (n_sgroups > (1 << 20)) { set_error("sampler: batch too large for one launch"); return FINROM_ERR_UNSUPPORTED; }
   const unsigned grid = (unsigned)((n_super + 7) / 8 * 8 * 8 * G::SM_PER_SUPER);
   hipLaunchKernelGGL(sampler_gemm_kernel<WM>, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, st, U, n, xi, S, k, (int)n_sgroups, n_cgroups,
-                     ntn - 1, pad ? 1 : 0);
+                     ntn - 1, pad ? (getenv("FINROM_SAMPLER_PAD_GROUPS") ? atoi(getenv("FINROM_SAMPLER_PAD_GROUPS")) : 1 << 20) : 0,
+                     getenv("FINROM_SAMPLER_XFLAGS") ? atoi(getenv("FINROM_SAMPLER_XFLAGS")) : 0);
   FR_HIP(hipGetLastError());
   return 0;
 }

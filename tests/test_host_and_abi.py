@@ -179,6 +179,33 @@ def test_bench_gpus2_launches_two_ranks_and_matches_single_process():
     assert nine["n_gpus"] == 2
 
 
+def test_hmc_entry_points_validate_their_state_before_any_device_call():
+    """finrom_hmc_begin / _leapfrog / _end reject a state with null fields, a negative step and a field size that is not the error
+    model's with FINROM_ERR_ARG and a message -- host-side checks, no GPU needed."""
+    import ctypes as C
+    from bayesianinferencedl_amd import _ffi
+    L = _ffi.lib()
+    st = _ffi.HmcState(C=2, n=8, eps=0.1, c_lik=1.0, c_pri=1.0)
+    assert L.finrom_hmc_begin(C.byref(st), None) == -1 and b"null field" in L.finrom_last_error()
+    assert L.finrom_hmc_end(C.byref(st), 10, None) == -1
+    assert L.finrom_hmc_leapfrog(None, None, None, C.byref(st), 0, None, 0, None, None, None, None) == -1
+    assert L.finrom_hmc_begin(None, None) == -1
+    assert L.finrom_deferred_count() == 0 and L.finrom_flush_deferred() == 0 and L.finrom_note_stream(None) == 0
+
+
+def test_build_dependencies_follow_the_includes():
+    """_build._deps: a source is rebuilt when a header it includes (transitively) changes -- and only then: the band sweep's
+    translation units (minutes each) do not depend on the reduced model's headers."""
+    import os
+    from bayesianinferencedl_amd import _build as B
+    deps = {s_: {os.path.basename(d) for d in B._deps(os.path.join(B.CSRC, s_))} for s_ in B.SOURCES}
+    assert {"finrom_core.h", "fom_band_device.h", "finrom.h"} <= deps["fom_band.hip"] and "finrom_internal.h" not in deps["fom_band.hip"]
+    assert "fom_band.hip" in deps["fom_band_wide.hip"]
+    assert {"finrom_internal.h", "finrom_core.h", "rom_proj_device.h", "mlp_device.h"} <= deps["rom_onesample.hip"]
+    assert all("finrom_core.h" in d for d in deps.values())
+    assert set(B.SOURCES) == {f for f in os.listdir(B.CSRC) if f.endswith(".hip")}
+
+
 def test_bench_hmc_chain_deal_and_gather_over_two_ranks():
     """configs[4]'s multi-rank form on CPU (`--workload hmc --gpus 2 --dry-run`): chains dealt round robin (rank g owns g, g + N, ...),
     end states / accept counts / traces gathered on rank 0 in chain order; the checksums must equal the one-process run's, also when

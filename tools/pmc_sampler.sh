@@ -6,7 +6,7 @@ tag=$1; S=${2:-20000}; n=${3:-4101}
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 out=gpurun_out/pmc_sampler_$tag
 mkdir -p $out
-for v in small_64x64 gemm_256x128 gemm_128x128 gemm_128x128_nopad; do
+for v in small_64x64 gemm_256x128 pad_top2 pad_top3 gemm_256x128_nopad; do
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     i=$((i+1))
@@ -16,7 +16,7 @@ done
 python - "$out" <<'PY'
 import csv, glob, sys, re, os, json
 res = {}
-for v in ("small_64x64", "gemm_256x128", "gemm_128x128", "gemm_128x128_nopad"):
+for v in ("small_64x64", "gemm_256x128", "pad_top2", "pad_top3", "gemm_256x128_nopad"):
     raw = {}
     for f in glob.glob(os.path.join(sys.argv[1], v, "g*", "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):

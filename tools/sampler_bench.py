@@ -26,11 +26,17 @@ res = {}
 for tag, env in (("small_64x64", {"FINROM_SAMPLER_GEMM_MIN": str(1 << 40)}),
                  ("gemm_256x128", {"FINROM_SAMPLER_GEMM_MIN": "1"}),
                  ("gemm_256x128_nopad", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_NO_PAD": "1"}),
+                 ("pad_top1", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_PAD_GROUPS": "1"}),
+                 ("pad_top2", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_PAD_GROUPS": "2"}),
+                 ("pad_top3", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_PAD_GROUPS": "3"}),
+                 ("x_nobarrier", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_XFLAGS": "1"}),
+                 ("x_nostaging", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_XFLAGS": "2"}),
+                 ("x_neither", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_XFLAGS": "3"}),
                  ("gemm_128x128", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_WM": "2"}),
                  ("gemm_128x128_nopad", {"FINROM_SAMPLER_GEMM_MIN": "1", "FINROM_SAMPLER_NO_PAD": "1", "FINROM_SAMPLER_WM": "2"})):
     if only and tag != only:
         continue
-    for k in ("FINROM_SAMPLER_GEMM_MIN", "FINROM_SAMPLER_NO_PAD", "FINROM_SAMPLER_WM"):
+    for k in ("FINROM_SAMPLER_GEMM_MIN", "FINROM_SAMPLER_NO_PAD", "FINROM_SAMPLER_WM", "FINROM_SAMPLER_XFLAGS", "FINROM_SAMPLER_PAD_GROUPS"):
         os.environ.pop(k, None)
     os.environ.update(env)
     out = smp(xi)
@@ -47,4 +53,4 @@ for tag, env in (("small_64x64", {"FINROM_SAMPLER_GEMM_MIN": str(1 << 40)}),
     tf = S * float(n) * n / (ms / cnt * 1e-3) / 1e12
     print(f"{tag}: {ms / cnt:.3f} ms per launch ({wall * 1e3:.3f} wall), {tf:.1f} TFLOP/s useful = {tf / 78.6:.3f} of peak", flush=True)
 if not only:
-    print("bit-identical:", [bool(torch.equal(res["small_64x64"], v)) for v in res.values()])
+    print("bit-identical:", {k_: bool(torch.equal(res["small_64x64"], v)) for k_, v in res.items()})
