@@ -27,20 +27,29 @@ pmc_pass() {   # <subdir> <bench args...>: HBM / L2 / SQ counter groups, halves 
   done
 }
 echo "[2] headline counters"; pmc_pass headline || exit 1
-echo "[3] counters + kernel trace with the halves side by side (overlap check)"
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES \
-  --output-format csv -d $out/pmc_overlap_check -o run -- python $B1 > $out/pmc_overlap_check.log 2>&1 || echo "  (overlap check pass failed: see log)"
+# ([3] of round 3 -- counters + kernel trace side by side -- answered its question: rocprofv3 serialises the kernels while it collects
+#  counters, profiles/r03_overlap_pmc.json; not repeated)
 echo "[4] configs[2] nine / r = 120"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c3 -o run -- python $B $C3 > $out/bench_c3.log 2>&1 || exit 1
 pmc_pass c3 $C3 || exit 1
 echo "[5] configs[3] field / m = 20 / r = 200 (20k of the 125k shard)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c4 -o run -- python $B $C4 > $out/bench_c4.log 2>&1 || exit 1
 pmc_pass c4 $C4 || exit 1
+echo "[5b] the full 125k shard of configs[3]: HBM counters only (two pieces of 62.5k per step)"
+mkdir -p $out/c4full
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  d=$out/c4full/pmc_$(echo $grp | tr ' ' '_')
+  FINROM_NO_OVERLAP=1 rocprofv3 --pmc $grp --output-format csv -d $d -o run -- python $B1 --params field --m 20 --r 200 --samples 125000 > $d.log 2>&1 || { echo "pmc c4full $grp failed"; tail -3 $d.log; exit 1; }
+  echo "  pmc [c4full] $grp done"
+done
 echo "[6] offline/online form, HMC rehearsal, full cfg4 shard"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/oo_overlapped -o run -- python $B --projection offline_online > $out/bench_oo_overlapped.log 2>&1 || exit 1
-python bench.py --workload hmc --steps 10000 --warmup 100 > $out/bench_hmc.log 2>&1 || exit 1
+python bench.py --workload hmc --steps 10000 --warmup 100 --hmc-trace > $out/bench_hmc.log 2>&1 || exit 1      # (with cpu_baseline: default --cpu-samples)
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/hmc -o run -- python bench.py --workload hmc --steps 1000 --warmup 50 --cpu-samples 0 > $out/bench_hmc_traced.log 2>&1 || exit 1
 python tools/hmc_timeline.py $out/hmc/run_kernel_trace.csv > $out/hmc_timeline.txt 2>&1; rm -f $out/hmc/run_kernel_trace.csv
 python bench.py --steps 2 --warmup 1 --cpu-samples 0 --no-host-io --no-other --params field --m 20 --r 200 --samples 125000 > $out/bench_c4_full.log 2>&1 || exit 1
+FINROM_NO_OVERLAP=1 python bench.py --steps 2 --warmup 1 --cpu-samples 0 --no-host-io --no-other --params field --m 20 --r 200 --samples 125000 > $out/bench_c4_full_in_turn.log 2>&1 || exit 1
+echo "[7] the driver's own command"
+python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_final.log 2>&1 || exit 1
 python tools/pmc_summary.py $out > $out/summary.log 2>&1
 cat $out/summary.log

@@ -11,7 +11,8 @@ import re
 import sys
 
 out = sys.argv[1]
-WORKLOADS = {"headline": "five/m12/r80/S100000", "c3": "nine/m12/r120/S100000", "c4": "field/m20/r200/S20000"}
+WORKLOADS = {"headline": "five/m12/r80/S100000", "c3": "nine/m12/r120/S100000", "c4": "field/m20/r200/S20000",
+             "c4full": "field/m20/r200/S125000"}
 SLOT_OF = {"fom_band_kernel": "fom_chol_solve", "fom_band_ldsw_kernel": "fom_chol_solve", "fom_vm_kernel": "fom_chol_solve",
            "fom_bwd_kernel": "fom_chol_solve", "fom_small_kernel": "fom_chol_solve", "rom_gram_kernel": "rom_proj_mfma",
            "rom_gram_store_kernel": "rom_proj_mfma", "fom_assemble_kernel": "fom_assemble", "rom_proj_kernel": "rom_proj_mfma",
@@ -36,7 +37,7 @@ for sub, key in WORKLOADS.items():
                     raw.setdefault(k, {})[row["Counter_Name"]] = float(row["Counter_Value"])     # last launch wins
     if not raw:
         continue
-    summary = {"workload_key": key,
+    summary = {"workload_key": key, "commit": os.environ.get("FINROM_COMMIT"),
                "note": "rocprofv3 --pmc passes (one counter group per run, no tracing, halves in turn: FINROM_NO_OVERLAP=1) of "
                        "`bench.py --steps 1 --warmup 1 --cpu-samples 0 --no-profile` + the workload's flags; values of the last launch "
                        "of each kernel.  FETCH_SIZE/WRITE_SIZE in KiB; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 "
