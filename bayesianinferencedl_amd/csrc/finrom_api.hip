@@ -215,7 +215,7 @@ int finrom_set_device(int ordinal) { FR_HIP(hipSetDevice(ordinal)); return 0; }
 // buffer carries the event finrom_free_async recorded behind its last user; the next owner waits for it.
 namespace {
 constexpr size_t kPoolMaxEach = (size_t)16 << 20, kPoolMaxTotal = (size_t)256 << 20;
-struct Parked { void* p; hipEvent_t ev; };
+struct Parked { void* p; hipEvent_t ev; int dev; };       // (dev: a parked buffer is only handed out on the device it lives on)
 std::mutex g_pool_mu;
 std::vector<std::pair<void*, size_t>> g_pool_live;          // pooled allocations handed out: (pointer, size class)
 std::vector<std::pair<size_t, Parked>> g_pool_free;         // parked: (size class, buffer)
@@ -232,11 +232,13 @@ int finrom_malloc(void** dptr, size_t bytes) {
   const bool capture = any_capture();
   if (!capture) flush_deferred();
   size_t cap = bytes;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
   if (bytes <= kPoolMaxEach) {
     cap = size_class(bytes);
     std::unique_lock<std::mutex> lk(g_pool_mu);
     for (size_t i = g_pool_free.size(); i-- > 0;) {          // (the most recently parked first)
-      if (g_pool_free[i].first != cap) continue;
+      if (g_pool_free[i].first != cap || g_pool_free[i].second.dev != dev) continue;
       Parked b = g_pool_free[i].second;
       bool done = b.ev == nullptr;
       if (!done) { done = hipEventQuery(b.ev) == hipSuccess; if (!done) (void)hipGetLastError(); }
@@ -284,9 +286,12 @@ static int pool_free(void* dptr, hipStream_t stream, bool have_stream) {
       if (ev == nullptr) cap = 0;                              // no event to be had: do not park, free (deferred under capture)
     }
     if (cap != 0) {
+      int dev = 0;
+      hipPointerAttribute_t at{};
+      if (hipPointerGetAttributes(&at, dptr) == hipSuccess) dev = at.device; else { (void)hipGetLastError(); (void)hipGetDevice(&dev); }
       std::lock_guard<std::mutex> lk(g_pool_mu);
       if (g_pool_free_bytes + cap <= kPoolMaxTotal) {
-        g_pool_free.push_back({cap, Parked{dptr, ev}});
+        g_pool_free.push_back({cap, Parked{dptr, ev, dev}});
         g_pool_free_bytes += cap;
         return 0;
       }
