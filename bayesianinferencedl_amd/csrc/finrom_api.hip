@@ -191,7 +191,12 @@ struct finrom_rom_s {
   bool info_store = false;             // (same path) the solve kernel stores info instead of or-ing into it
 };
 struct finrom_sampler_s { double* U = nullptr; int n = 0; Scratch xi; };
-struct finrom_mlp_s { MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp, g0; };
+struct finrom_mlp_s {
+  MlpDev d{}; std::vector<void*> owned; Scratch tape, theta, gth, shift, qtmp, etmp, g0, y0p, thp;
+  // finrom_hmc_leapfrog: the partial sums of theta the last step left in thp, and the field they belong to (position buffer,
+  // momentum buffer, step size, chains): the next step uses them only if it is that field's step
+  const double* carry_k = nullptr; const double* carry_mom = nullptr; double carry_eps = 0.0; int64_t carry_S = 0;
+};
 
 template <class T>
 static int up(std::vector<void*>& owned, const T** dst, const T* host, size_t count) {
@@ -1655,7 +1660,7 @@ int finrom_mlp_create(const finrom_mlp_desc* a, finrom_mlp_t* out) {
 void finrom_mlp_destroy(finrom_mlp_t h) {
   if (!h) return;
   for (void* p : h->owned) dev_free(p);
-  h->tape.release(); h->theta.release(); h->gth.release(); h->shift.release(); h->qtmp.release(); h->etmp.release(); h->g0.release();
+  h->tape.release(); h->theta.release(); h->gth.release(); h->shift.release(); h->qtmp.release(); h->etmp.release(); h->g0.release(); h->y0p.release(); h->thp.release();
   delete h;
 }
 int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, void* stream) {
@@ -1666,7 +1671,7 @@ int finrom_mlp_predict(finrom_mlp_t h, const double* k, int64_t S, double* e, vo
   return launch_mlp_forward(h->d, k, S, nullptr, 0, (float*)h->tape.p, e, nullptr, (hipStream_t)stream);
 }
 // (hs: the call is a leapfrog step -- finrom_hmc_leapfrog: position update in front, momentum update behind; one-sample form only)
-struct HmcStep { const double* mom; double eps; double* k_out; HmcTail tail; };
+struct HmcStep { const double* mom; double eps; double* k_out; HmcTail tail; const double* theta_parts_in; };
 static int romml_grad_impl(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, const double* k, const double* data,
                            int32_t data_per_sample, int64_t S, double* grad, double* loss, double* qoi_r, double* e_nn,
                            int32_t* info, void* stream, const HmcStep* hs) {
@@ -1698,10 +1703,12 @@ static int romml_grad_impl(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop
     return FINROM_ERR_UNSUPPORTED;
   }
   MlpFuse fm;
-  if (hs != nullptr) { fm.mom = hs->mom; fm.eps = hs->eps; fm.k_out = hs->k_out; }
+  if (hs != nullptr) { fm.mom = hs->mom; fm.eps = hs->eps; fm.k_out = hs->k_out; fm.theta_parts = hs->theta_parts_in; }
   if (one && P <= 16) {                                // the network's forward pass and theta = S k ride in the ROM's contraction kernel
     fm.on = 1; fm.m = m; fm.k = k; fm.data = data; fm.data_stride = stride; fm.tape = (float*)mlp->tape.p; fm.e_out = e_nn;
     fm.data_shift = (double*)mlp->shift.p;
+    if ((rc = mlp->y0p.reserve((size_t)S * fm.nw0 * 64 * sizeof(float)))) return rc;
+    fm.y0_part = (float*)mlp->y0p.p;
     fm.Sop = Sop; fm.P = P; fm.theta_out = (double*)mlp->theta.p; fm.theta_scr = (double*)mlp->theta.p + (size_t)S * P;
   } else if (P <= 16) {
     if ((rc = launch_mlp_forward(m, k, S, data, stride, (float*)mlp->tape.p, e_nn, (double*)mlp->shift.p, st, Sop, P, (double*)mlp->theta.p))) return rc;
@@ -1773,9 +1780,19 @@ int finrom_hmc_leapfrog(finrom_rom_t rom, finrom_mlp_t mlp, const double* Sop, c
   if (a->c_pri == 0.0) { set_error("hmc_leapfrog: c_pri = 0"); return FINROM_ERR_ARG; }
   HmcStep hs;
   hs.mom = a->P; hs.eps = a->eps; hs.k_out = a->Kq[(step + 1) & 1];
+  // theta of THIS step's field from the previous step's momentum update, when this is that field's step (not the first step of a
+  // trajectory: finrom_hmc_begin has no averaging operator at hand); and this step leaves the next one's
+  if (int rc = mlp->thp.reserve((size_t)a->C * HMC_THETA_PARTS * 16 * sizeof(double))) return rc;
+  const bool carried = step > 0 && mlp->carry_k == a->Kq[step & 1] && mlp->carry_mom == a->P && mlp->carry_eps == a->eps &&
+                       mlp->carry_S == a->C && getenv("FINROM_HMC_NO_CARRY") == nullptr;
+  hs.theta_parts_in = carried ? (const double*)mlp->thp.p : nullptr;
+  hs.tail.eps = a->eps; hs.tail.theta_parts = rom->d.P <= HMC_THETA_MAXP ? (double*)mlp->thp.p : nullptr;
+  mlp->carry_k = nullptr;
   hs.tail.on = 1; hs.tail.kq = hs.k_out; hs.tail.mean = a->mean; hs.tail.mom = a->P; hs.tail.dU = a->dUq;
   hs.tail.coef = a->c_lik / a->c_pri; hs.tail.eps_cpri = a->eps * a->c_pri; hs.tail.info = a->info;
-  return romml_grad_impl(rom, mlp, Sop, a->Kq[step & 1], data, data_per_sample, a->C, grad_out, a->loss, qoi_r, e_nn, a->info, stream, &hs);
+  const int rc = romml_grad_impl(rom, mlp, Sop, a->Kq[step & 1], data, data_per_sample, a->C, grad_out, a->loss, qoi_r, e_nn, a->info, stream, &hs);
+  if (rc == 0 && hs.tail.theta_parts != nullptr) { mlp->carry_k = hs.k_out; mlp->carry_mom = a->P; mlp->carry_eps = a->eps; mlp->carry_S = a->C; }
+  return rc;
 }
 
 int finrom_sub(const double* a, const double* b, int64_t count, double* out, void* stream) {

@@ -26,13 +26,25 @@ struct MlpFuse {
   // finrom_hmc_leapfrog: the position update rides in front -- every reader of the field sees k + eps * mom, and the network's
   // workgroup (which reads all of it anyway) writes the moved field to k_out (NOT in place: the sample's other workgroups read k)
   const double* mom = nullptr; double eps = 0.0; double* k_out = nullptr;
+  // round 4: the first layer over nw0 spare workgroups (partial sums y0_part [S x nw0 x 64] floats), the layers behind it as a
+  // spare wave of the solve kernel (rom_onesample.hip)
+  int nw0 = 4; float* y0_part = nullptr;
+  // finrom_hmc_leapfrog, steps behind the first of a trajectory: theta = S (k + eps mom) arrives as HMC_THETA_PARTS partial sums
+  // [S x HMC_THETA_PARTS x 16] left by the previous step's momentum update (which forms the new momentum anyway) -- the 4.6 us theta
+  // phase at the head of every contraction workgroup becomes one load of 8 x P doubles
+  const double* theta_parts = nullptr;
 };
+constexpr int HMC_THETA_PARTS = 8;      // = mlp_kernels.hip's MLP_SPLIT: one partial sum per workgroup of the backward kernel
+constexpr int HMC_THETA_MAXP = 10;      // averages the carry handles (the fin has nine); beyond: every step forms theta itself
 // finrom_hmc_leapfrog: the momentum update rides behind the gradient (mlp_backward_kernel's epilogue):
 //   dU = (kq - mean) + coef * grad  (0 for a flagged sample);  mom -= eps_cpri * dU
 struct HmcTail {
   int on = 0;
   const double* kq = nullptr; const double* mean = nullptr; double* mom = nullptr; double* dU = nullptr;
   double coef = 0.0, eps_cpri = 0.0; const int* info = nullptr;
+  // the NEXT step's sub-fin averages while the new momentum is at hand: theta_parts[s][wg][p] = sum over this workgroup's rows of
+  // Sop[p][i] (kq[i] + eps mom_new[i]); nullptr: not wanted
+  double eps = 0.0; double* theta_parts = nullptr;
 };
 int launch_mlp_forward(const MlpDev& m, const double* k, int64_t S, const double* data, int64_t data_stride, float* tape,
                        double* e_out, double* data_shift, hipStream_t st, const double* Sop = nullptr, int P = 0,

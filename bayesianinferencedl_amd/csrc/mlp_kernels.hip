@@ -16,7 +16,7 @@ constexpr int MLP_PARTS = 16;        // threads per hidden unit in the first lay
                                      // 1597 x 50 dependent-load multiply-adds per sample and the call is latency-bound -- 100 rows
                                      // per thread, 32 loads in flight, instead of 400 rows with 4 parts: 28 -> ~10 us)
 constexpr int MLP_THREADS = 64 * MLP_PARTS;
-constexpr int MLP_SPLIT = 8;         // workgroups per sample in the backward kernel's one-sample form ...
+constexpr int MLP_SPLIT = HMC_THETA_PARTS;      // (8) workgroups per sample in the backward kernel's one-sample form ...
 constexpr int MLP_SPLIT_MAX_S = 64;  // ... which serves calls of up to this many samples
 
 __global__ __launch_bounds__(MLP_THREADS) void mlp_forward_kernel(MlpDev m, const double* __restrict__ k, int64_t S,
@@ -67,7 +67,22 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
   __syncthreads();                                     // g is final: the other waves join for the first layer's transpose
   const int wg = NP > 1 ? (int)blockIdx.y : 0;
   const int r0 = (int)((int64_t)m.n_in * wg / NP), r1 = (int)((int64_t)m.n_in * (wg + 1) / NP);
+  constexpr int TP = HMC_THETA_MAXP;                   // (the carried averages: at most this many -- registers; 1024 threads = 128 each)
+  const bool carry = ht.on && ht.theta_parts != nullptr && NP == HMC_THETA_PARTS;
+  double tpart[TP];
+#pragma unroll
+  for (int p = 0; p < TP; ++p) tpart[p] = 0.0;
   for (int i = r0 + tid; i < r1; i += MLP_THREADS) {
+    // everything this row needs from memory is requested up front (one trip): its column of Sop serves the chain rule AND the next
+    // step's sub-fin averages; the leapfrog's operands do not wait behind the product with W0
+    const int64_t idx = s * m.n_in + i;
+    double sv[TP];
+    if (carry) {
+#pragma unroll
+      for (int p = 0; p < TP; ++p) sv[p] = p < P ? Sop[(int64_t)p * m.n_in + i] : 0.0;
+    }
+    double kq_i = 0.0, mean_i = 0.0, mom_i = 0.0; int bad_s = 0;
+    if (ht.on) { kq_i = ht.kq[idx]; mean_i = ht.mean[idx]; mom_i = ht.mom[idx]; bad_s = ht.info[s]; }
     float acc = 0.f;
     {
       const float* __restrict__ wrow = m.W0 + (int64_t)i * nw;
@@ -84,13 +99,45 @@ __global__ __launch_bounds__(MLP_THREADS) void mlp_backward_kernel(MlpDev m, int
       acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     }
     double out = -(double)acc;                         // d loss / d input = -vjp(r)
-    for (int p = 0; p < P; ++p) out = fma(gth[p], Sop[(int64_t)p * m.n_in + i], out);
-    if (grad != nullptr) grad[s * m.n_in + i] = out;
+    if (carry) {
+#pragma unroll
+      for (int p = 0; p < TP; ++p)
+        if (p < P) out = fma(gth[p], sv[p], out);
+    } else {
+      for (int p = 0; p < P; ++p) out = fma(gth[p], Sop[(int64_t)p * m.n_in + i], out);
+    }
+    if (grad != nullptr) grad[idx] = out;
     if (ht.on) {                                       // the leapfrog's momentum update behind the gradient (finrom_hmc_leapfrog)
-      const int64_t idx = s * m.n_in + i;
-      const double du = ht.info[s] != 0 ? 0.0 : fma(ht.coef, out, ht.kq[idx] - ht.mean[idx]);
+      const double du = bad_s != 0 ? 0.0 : fma(ht.coef, out, kq_i - mean_i);
       ht.dU[idx] = du;
-      ht.mom[idx] = fma(-ht.eps_cpri, du, ht.mom[idx]);
+      const double pn = fma(-ht.eps_cpri, du, mom_i);
+      ht.mom[idx] = pn;
+      if (carry) {                                     // the next step's field, exactly as its kernels will form it
+        const double kn = fma(ht.eps, pn, kq_i);
+#pragma unroll
+        for (int p = 0; p < TP; ++p)
+          if (p < P) tpart[p] = fma(sv[p], kn, tpart[p]);
+      }
+    }
+  }
+  if (carry) {                                          // this workgroup's partial sums, waves in index order
+    __shared__ double tw[MLP_THREADS / 64][16];
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nwv = (r1 - r0 + 63) / 64 < MLP_THREADS / 64 ? (r1 - r0 + 63) / 64 : MLP_THREADS / 64;      // waves that hold rows (4 of 16 at n = 1597)
+    if (wave < nwv) {
+#pragma unroll
+      for (int p = 0; p < TP; ++p)
+        if (p < P) {
+          double x = tpart[p];
+          for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+          if (lane == 0) tw[wave][p] = x;
+        }
+    }
+    __syncthreads();
+    if (tid < P) {
+      double t = 0.0;
+      for (int w = 0; w < nwv; ++w) t += tw[w][tid];
+      ht.theta_parts[(s * HMC_THETA_PARTS + wg) * 16 + tid] = t;
     }
   }
 }

@@ -37,11 +37,13 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t s = blockIdx.x;
   const int j = blockIdx.y;
-  // workgroup NC of a sample (finrom_romml_grad only): the learned error model's forward pass, which this contraction does not
-  // depend on -- as a kernel of its own it was 19 us at the head of the one-sample call, here it ends with the contraction
-  if (fm.on && j == NC) {
-    mlp_forward_body<256>(fm.m, fm.k, s, fm.data, fm.data_stride, fm.tape, fm.e_out, fm.data_shift, nullptr, 0, nullptr,
-                          (float*)red_lds, (int)threadIdx.x, fm.mom, fm.eps, fm.k_out);
+  // workgroups NC .. of a sample (finrom_romml_grad only): the learned error model's FIRST LAYER, which this contraction does not
+  // depend on -- as a kernel of its own the forward pass was 19 us at the head of the one-sample call; as ONE spare workgroup here
+  // (round 3) it took as long as the contraction (25 us); now nw0 workgroups take a share of the rows each and the layers behind
+  // are a spare wave of the solve kernel (mlp_device.h)
+  if (fm.on && j >= NC) {                               // (workgroups NC .. NC + nw0 - 1: their rows of the network's first layer)
+    mlp_first_layer_part<256>(fm.m, fm.k, s, fm.mom, fm.eps, fm.k_out, j - NC, fm.nw0, fm.y0_part + (s * fm.nw0 + (j - NC)) * 64,
+                              (float*)red_lds, (int)threadIdx.x);
     return;
   }
   const int q = lane >> 4, c = lane & 15;
@@ -52,6 +54,21 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
     // (stores acknowledged by L2, then the scalar cache invalidated).
     __shared__ double th_part[4][16];
     const int n = fm.m.n_in, P = fm.P;
+    double* __restrict__ tscr = fm.theta_scr + (s * NC + j) * 16;
+    if (fm.theta_parts != nullptr) {                     // (a leapfrog step behind the first: the previous step left the sums)
+      if ((int)threadIdx.x < P) {
+        const int pp = threadIdx.x;
+        const double* tp = fm.theta_parts + s * (HMC_THETA_PARTS * 16) + pp;
+        double v[HMC_THETA_PARTS];
+#pragma unroll
+        for (int w = 0; w < HMC_THETA_PARTS; ++w) v[w] = tp[w * 16];
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < HMC_THETA_PARTS; ++w) t += v[w];
+        tscr[pp] = t;
+        if (j == 0) fm.theta_out[s * P + pp] = t;
+      }
+    } else {
     const double* __restrict__ krow = fm.k + s * (int64_t)n;
     const double* __restrict__ mrow = fm.mom != nullptr ? fm.mom + s * (int64_t)n : nullptr;      // (leapfrog: the field is k + eps * mom)
     const int i0 = (int)((int64_t)n * wave / 4), i1 = (int)((int64_t)n * (wave + 1) / 4);
@@ -88,12 +105,12 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
         if (lane == 0) th_part[wave][pp] = x;
       }
     __syncthreads();
-    double* __restrict__ tscr = fm.theta_scr + (s * NC + j) * 16;
     if ((int)threadIdx.x < P) {
       const int pp = threadIdx.x;
       const double t = ((th_part[0][pp] + th_part[1][pp]) + th_part[2][pp]) + th_part[3][pp];
       tscr[pp] = t;
       if (j == 0) fm.theta_out[s * P + pp] = t;
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -137,13 +154,14 @@ __global__ __launch_bounds__(256, 1) void rom_small_proj_kernel(RomDev p, const 
 typedef double v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4d mma(double a, double b, v4d cacc) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, cacc, 0, 0, 0); }
 
-template <int NB> constexpr int small_solve_lds() { return onesample_nt<NB>() * 256 + 2 * NB * 256 + 16 * NB + 32 + 32; }
+constexpr int MLP_STAGE_FLOATS = 16 * 256 * 4;      // what 256 threads stage with 16 four-float loads each: 64 KB (5 x 50 x 50 + 50 x 9 = 12 950 floats fit)
+template <int NB> constexpr int small_solve_lds(bool mlp = false) { return onesample_nt<NB>() * 256 + 2 * NB * 256 + 16 * NB + 32 + 32 + 32 + 64 + 2 + (mlp ? MLP_STAGE_FLOATS / 2 : 0); }
 
 template <int NB>
-__global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const double* __restrict__ theta, int64_t S, int NC,
+__global__ __launch_bounds__(320, 1) void rom_small_solve_kernel(RomDev p, const double* __restrict__ theta, int64_t S, int NC,
                                                                  const double* __restrict__ part, int grad, RomGradArgs ga,
                                                                  double* __restrict__ w_r, double* __restrict__ qoi_r,
-                                                                 int* __restrict__ info) {
+                                                                 int* __restrict__ info, MlpFuse fm) {
   constexpr int NT = onesample_nt<NB>();
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* __restrict__ tl = lds;                      // [NT][256] A tiles, overwritten by U tiles; natural layout (row * 16 + col)
@@ -151,6 +169,10 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
   double* __restrict__ zl = mbuf + NB * 256;          // [NB][256] the extra tile column Z, natural layout
   double* __restrict__ bl = zl + NB * 256;            // [16 NB] B_r
   double* __restrict__ th = bl + 16 * NB;             // [32] 1, theta_1..P, 0
+  double* __restrict__ dsh = th + 32;                 // [32] data - e_NN of this sample (the spare wave's hand-over, fm.on)
+  float* __restrict__ mlp_y = (float*)(dsh + 32);     // [64] + [64] floats: the spare wave's layer vectors
+  int* __restrict__ mlp_flag = (int*)(mlp_y + 128);   // arrivals of the four staging waves (+ 3 ints of padding)
+  float* __restrict__ mlp_wl = mlp_y + 128 + 4;       // [MLP_STAGE_FLOATS] the error model's hidden + head weights (fm.on)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t s = blockIdx.x;
   const int q = lane >> 4, c = lane & 15;
@@ -163,7 +185,62 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
   // trip -- the first version -- made this phase 12 of the kernel's 50 us)
   {
     constexpr int TB = 3, JB = 8;
-    for (int t0 = wave; t0 < NT; t0 += 4 * TB) {
+    // (wave 4 exists in finrom_romml_grad's one-sample form only: the error model's layers behind the first, whose result -- the
+    //  adjoint's data, data - e_NN -- wave 0 needs at the middle of the kernel; it meets the others at every barrier)
+    // Its weights (52 KB, cold: every batch of them fetched by a lone wave was a trip beyond L2, the walk 30 us) are STAGED in LDS
+    // by waves 0 .. 3 -- sixteen 16-byte loads per lane, all in flight at once, in front of their own partial-sum loads -- and wave 4
+    // waits for the four arrivals on an LDS counter (the hardware barrier would tie the others to it; the counter is zeroed behind
+    // a barrier at the kernel's first instruction, when nobody has anything to wait for)
+    const int n_stage = fm.on ? fm.m.n_layers * fm.m.n_w * fm.m.n_w + fm.m.n_w * fm.m.n_out : 0;
+    const bool staged = fm.on && n_stage <= MLP_STAGE_FLOATS && ((fm.m.n_layers * fm.m.n_w * fm.m.n_w) & 3) == 0;
+    if (fm.on) {
+      if (threadIdx.x == 0) *mlp_flag = 0;
+      __syncthreads();
+      if (staged && wave < 4) {
+        typedef float f4_t __attribute__((ext_vector_type(4)));
+        const int nh4 = (fm.m.n_layers * fm.m.n_w * fm.m.n_w) >> 2, nt4 = (n_stage + 3) >> 2;
+        f4_t v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int c4 = (int)threadIdx.x + 256 * u;
+          f4_t x = (f4_t){0.f, 0.f, 0.f, 0.f};
+          if (c4 < nh4) x = ((const f4_t*)fm.m.W)[c4];
+          else if (c4 < nt4) {                             // the head (its start need not be 16-byte aligned in the staged array)
+            const int e = 4 * (c4 - nh4), ne = fm.m.n_w * fm.m.n_out;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) x[t] = e + t < ne ? fm.m.Wh[e + t] : 0.f;
+          }
+          v[u] = x;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int c4 = (int)threadIdx.x + 256 * u;
+          ((f4_t*)mlp_wl)[c4] = v[u];                      // (beyond the weights: zeros -- the unguarded loops may read there)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(mlp_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    if (wave == 4) {
+#ifdef FINROM_SOLVE_CLOCKS
+      const long long w4a = wall_clock64();
+#endif
+      if (staged) {
+        while (__hip_atomic_load(mlp_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+#ifdef FINROM_SOLVE_CLOCKS
+      const long long w4b = wall_clock64();
+#endif
+      if (staged) mlp_forward_tail_wave<true>(fm.m, s, fm.y0_part + s * fm.nw0 * 64, fm.nw0, fm.data, fm.data_stride, fm.tape, fm.e_out,
+                                              fm.data_shift, dsh, mlp_y, mlp_y + 64, lane, mlp_wl);
+      else mlp_forward_tail_wave<false>(fm.m, s, fm.y0_part + s * fm.nw0 * 64, fm.nw0, fm.data, fm.data_stride, fm.tape, fm.e_out,
+                                        fm.data_shift, dsh, mlp_y, mlp_y + 64, lane, nullptr);
+#ifdef FINROM_SOLVE_CLOCKS
+      if (lane == 0) { dsh[30] = (double)(w4b - w4a); dsh[31] = (double)(wall_clock64() - w4b); }
+#endif
+    }
+    for (int t0 = wave; t0 < NT && wave < 4; t0 += 4 * TB) {
       double a[TB][4];
 #pragma unroll
       for (int u = 0; u < TB; ++u)
@@ -198,7 +275,9 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
     if (lane == 0) { th[0] = 1.0; th[p.P + 1] = 0.0; }
     if (lane < p.P) th[lane + 1] = theta[s * p.P + lane];
   }
-  __syncthreads();
+  // (no barrier here: B_r is wave 0's work on wave 0's own th[]; the tiles of the other waves are first read behind the barrier
+  //  below -- which is also where the error model's spare wave has to have arrived: it has partial sums + B_r, ~9 us, to finish)
+  wave_sync();
 #ifdef FINROM_SOLVE_CLOCKS
   ck[1] = wall_clock64();
 #endif
@@ -292,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
 #ifdef FINROM_SOLVE_CLOCKS
       ck[6] += wall_clock64() - cd0;
 #endif
-    } else {
+    } else if (wave <= 3) {
 #pragma unroll
       for (int sl = 0; sl < 2; ++sl) {
         const int item = (wave - 1) + 3 * sl;            // 0 .. NITEM - 1
@@ -360,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
       }
     }
     __syncthreads();                                     // M_kb is in LDS
-    if (wave > 0) {
+    if (wave > 0 && wave <= 3) {
       double Am[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) Am[g] = mbuf[kb * 256 + trn + 4 * g];      // Am[g] at lane (q, c) = M[c][q + 4 g]
@@ -403,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
   }
   if (qoi_r != nullptr && lane >= 1 && lane <= p.n_obs) qoi_r[s * p.n_obs + lane - 1] = bad ? nanv : part_q;
   if (grad) {
-    const double* dat = ga.data + (ga.data_stride ? s * ga.data_stride : 0);
+    const double* dat = fm.on ? dsh : ga.data + (ga.data_stride ? s * ga.data_stride : 0);      // (fm.on: from the spare wave, through LDS)
     const bool ocol = c >= 1 && c <= p.n_obs;
     const double res = ocol ? dat[c - 1] - part_q : 0.0;
     double r2 = (q == 0) ? res * res : 0.0;
@@ -441,6 +520,8 @@ __global__ __launch_bounds__(256, 1) void rom_small_solve_kernel(RomDev p, const
 #ifdef FINROM_SOLVE_CLOCKS
   ck[5] = wall_clock64();
   if (lane == 0 && qoi_r != nullptr) { for (int i = 0; i < 5; ++i) qoi_r[s * p.n_obs + i] = (double)(ck[i + 1] - ck[i]); qoi_r[s * p.n_obs + 5] = (double)ck[6]; }
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 10 && qoi_r != nullptr && fm.on) { qoi_r[s * p.n_obs + 6] = dsh[30]; qoi_r[s * p.n_obs + 7] = dsh[31]; }
 #endif
   const int R = p.rp;
   if (c <= 1) {                                         // column 0 of X is w_r, column 1 v_r
@@ -462,6 +543,7 @@ template <int NB>
 int launch_small(const RomDev& p, const double* theta, int64_t S, int NC, double* part, int grad, const RomGradArgs& ga, double* w_r,
                  double* qoi_r, int* info, hipStream_t st, const MlpFuse* fuse) {
   constexpr int lds_a = 3 * onesample_nt<NB>() * 256 * (int)sizeof(double), lds_b = small_solve_lds<NB>() * (int)sizeof(double);
+  constexpr int lds_b_mlp = small_solve_lds<NB>(true) * (int)sizeof(double);
   // the spare workgroup keeps the network's input (n_in floats) in the same dynamic LDS: a small basis' three partial triangles
   // can be smaller than that
   constexpr int lds_cap = lds_a > 96 * 1024 ? lds_a : 96 * 1024;
@@ -474,16 +556,17 @@ int launch_small(const RomDev& p, const double* theta, int64_t S, int NC, double
   static PerDeviceOnce once;
   if (int rc = once.run([&]() -> int {
         FR_HIP(hipFuncSetAttribute((const void*)rom_small_proj_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap));
-        FR_HIP(hipFuncSetAttribute((const void*)rom_small_solve_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b));
+        FR_HIP(hipFuncSetAttribute((const void*)rom_small_solve_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b_mlp));
         return 0; })) return rc;
   {
     ScopedKernelTimer t(K_ROM_PROJ, st);
-    hipLaunchKernelGGL(rom_small_proj_kernel<NB>, dim3((unsigned)S, (unsigned)(NC + (fm.on ? 1 : 0))), dim3(256), lds_launch, st, p, theta, S, NC, part,
+    hipLaunchKernelGGL(rom_small_proj_kernel<NB>, dim3((unsigned)S, (unsigned)(NC + (fm.on ? fm.nw0 : 0))), dim3(256), lds_launch, st, p, theta, S, NC, part,
                        p.kmeta, fm);
     FR_HIP(hipGetLastError());
   }
   ScopedKernelTimer t(K_ROM_SOLVE, st);
-  hipLaunchKernelGGL(rom_small_solve_kernel<NB>, dim3((unsigned)S), dim3(256), lds_b, st, p, theta, S, NC, part, grad, ga, w_r, qoi_r, info);
+  if (fm.on && !grad) { set_error("rom_onesample: the error model rides with the adjoint solve only"); return FINROM_ERR_ARG; }
+  hipLaunchKernelGGL(rom_small_solve_kernel<NB>, dim3((unsigned)S), dim3(fm.on ? 320 : 256), fm.on ? lds_b_mlp : lds_b, st, p, theta, S, NC, part, grad, ga, w_r, qoi_r, info, fm);
   FR_HIP(hipGetLastError());
   return 0;
 }

@@ -17,4 +17,4 @@ K=torch.from_numpy(np.exp(0.1*np.random.default_rng(0).standard_normal((4,V.dim(
 for _ in range(5):
     res=rom.grad_romml_batch(K)
 torch.cuda.synchronize()
-print("ticks of 10 ns: partial sums, B_r, forward, middle, backward, (diagonal chains inside forward):\n", res["qoi_r"].cpu().numpy()[:, :6])
+print("ticks of 10 ns: partial sums, B_r, forward, middle, backward, (diagonal chains inside forward):\n", res["qoi_r"].cpu().numpy()[:, :8], "\n(columns 6, 7: the spare wave's wait for the staged weights, its walk through the layers)")
