@@ -482,9 +482,13 @@ __global__ __launch_bounds__(320, 1) void rom_small_solve_kernel(RomDev p, const
   }
   if (qoi_r != nullptr && lane >= 1 && lane <= p.n_obs) qoi_r[s * p.n_obs + lane - 1] = bad ? nanv : part_q;
   if (grad) {
-    const double* dat = fm.on ? dsh : ga.data + (ga.data_stride ? s * ga.data_stride : 0);      // (fm.on: from the spare wave, through LDS)
     const bool ocol = c >= 1 && c <= p.n_obs;
-    const double res = ocol ? dat[c - 1] - part_q : 0.0;
+    // (fm.on: the data come from the spare wave through LDS.  Two loads under a uniform branch, NOT one pointer that selects between
+    //  the two address spaces: that would be a flat load)
+    double dval = 0.0;
+    if (fm.on) { if (ocol) dval = dsh[c - 1]; }
+    else { if (ocol) dval = ga.data[(ga.data_stride ? s * ga.data_stride : 0) + c - 1]; }
+    const double res = ocol ? dval - part_q : 0.0;
     double r2 = (q == 0) ? res * res : 0.0;
     for (int off = 8; off > 0; off >>= 1) r2 += __shfl_xor(r2, off);
     if (lane == 0) ga.J[s] = bad ? nanv : 0.5 * r2;
