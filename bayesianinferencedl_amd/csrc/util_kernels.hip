@@ -325,7 +325,7 @@ __device__ __forceinline__ void sampler_tile(const double* __restrict__ U, int n
 template <int WM>
 __global__ __launch_bounds__(128 * WM) void sampler_gemm_kernel(const double* __restrict__ U, int n, const double* __restrict__ xi,
                                                               int64_t S, double* __restrict__ kout, int n_sgroups, int n_cgroups,
-                                                              int top_tile, int pad_k, int xflags) {
+                                                              int top_tile, int pad_k, int pad_min_k, int xflags) {
   extern __shared__ __attribute__((aligned(16))) double sg_lds[];
   typedef SGeo<WM> G;
   constexpr int WGS = 8 * G::SM_PER_SUPER;               // workgroups of a super-tile = what one XCD runs together (32 CUs)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(128 * WM) void sampler_gemm_kernel(const double* __
   const int j0 = jt * 128;
   // lockstep (the whole super-tile to the top tile's K end) where the padding is cheap: column groups whose K end is >= 2048 -- below,
   // the 3.5 tiles of average padding are 20-40 % of the group's work and its strips are short anyway (6.81 -> 6.70 ms, +0.1 GB)
-  const int kend = min(n, ((cg < pad_k && (top + 1) * 128 >= 2048 ? top : jt) + 1) * 128);
+  const int kend = min(n, ((cg < pad_k && (top + 1) * 128 >= pad_min_k ? top : jt) + 1) * 128);
   const int nch = (kend + 15) / 16;
   const int live = (n - j0 - 64 * ((int)(threadIdx.x >> 6) & 1) + 15) / 16;     // this wave's column tiles that hold columns < n
   if (live >= 4) sampler_tile<WM, 4>(U, n, xi, S, kout, s0, j0, nch, sg_lds, xflags);
@@ -367,6 +367,7 @@ static int launch_sampler_gemm(const double* U, int n, const double* xi, int64_t
   const unsigned grid = (unsigned)((n_super + 7) / 8 * 8 * 8 * G::SM_PER_SUPER);
   hipLaunchKernelGGL(sampler_gemm_kernel<WM>, dim3(grid), dim3(G::THREADS), G::LDS_BYTES, st, U, n, xi, S, k, (int)n_sgroups, n_cgroups,
                      ntn - 1, pad ? (getenv("FINROM_SAMPLER_PAD_GROUPS") ? atoi(getenv("FINROM_SAMPLER_PAD_GROUPS")) : 1 << 20) : 0,
+                     getenv("FINROM_SAMPLER_PAD_GROUPS") ? 0 : 2048,      // (A/B: the first N column groups in lockstep whatever their K)
                      getenv("FINROM_SAMPLER_XFLAGS") ? atoi(getenv("FINROM_SAMPLER_XFLAGS")) : 0);
   FR_HIP(hipGetLastError());
   return 0;
