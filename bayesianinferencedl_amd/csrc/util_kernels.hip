@@ -10,24 +10,30 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // theta[s][p] = sum_j Sop[p][j] * k[s][j]   (fom/forward_solve.py:466-480, rom :404-418:
 // nine whole-mesh scalar assembles per sample in the reference; here one wave per sample)
 constexpr int MAXP = 16;
+// (round 4: SPW = 4 samples per wave share every value of Sop they load -- the operator is 9 x n doubles out of L2 per SAMPLE
+// otherwise, 5.9 GB of L2 -> CU traffic per 20 000 fields at n = 4101 against 0.66 GB of fields: 0.50 -> ~0.2 ms.  Each sample's
+// sums run in the same order as before: bit-identical.)
+template <int MAXP, int SUBFIN_SPW>      // (<10, 4> for the fin's nine averages: ~200 VGPRs, two waves per SIMD; <16, 2> beyond)
 __global__ __launch_bounds__(256) void subfin_avg_kernel(const double* __restrict__ Sop, int P, int n,
                                                          const double* __restrict__ k, int64_t S,
                                                          double* __restrict__ theta) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t s = (int64_t)blockIdx.x * 4 + wave;
-  if (s >= S) return;
-  double acc[MAXP];
+  const int64_t s0 = ((int64_t)blockIdx.x * 4 + wave) * SUBFIN_SPW;
+  if (s0 >= S) return;
+  double acc[SUBFIN_SPW][MAXP];
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) acc[p] = 0.0;
-  const double* ks = k + s * n;
-  // (four passes of 64 columns requested together -- one value of k and P of S per pass -- and added in the order of the
-  // columns, as before: the first version waited for every pass on its own, 25 dependent trips to memory for a 1597-node field --
-  // 34 us for one sample, and 0.4 TB/s for a batch of them)
+  for (int q = 0; q < SUBFIN_SPW; ++q)
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) acc[q][p] = 0.0;
+  // (four passes of 64 columns requested together -- one value of k per sample and P of S per pass -- and added in the order of the
+  // columns: the first version waited for every pass on its own, 25 dependent trips to memory for a 1597-node field)
   constexpr int UP = 4;
   for (int j0 = lane; j0 < n; j0 += 64 * UP) {
-    double kv[UP], sv[MAXP][UP];
+    double kv[SUBFIN_SPW][UP], sv[MAXP][UP];
 #pragma unroll
-    for (int u = 0; u < UP; ++u) kv[u] = j0 + 64 * u < n ? ks[j0 + 64 * u] : 0.0;
+    for (int q = 0; q < SUBFIN_SPW; ++q)
+#pragma unroll
+      for (int u = 0; u < UP; ++u) kv[q][u] = (j0 + 64 * u < n && s0 + q < S) ? k[(s0 + q) * n + j0 + 64 * u] : 0.0;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p)
       if (p < P) {
@@ -35,19 +41,23 @@ __global__ __launch_bounds__(256) void subfin_avg_kernel(const double* __restric
         for (int u = 0; u < UP; ++u) sv[p][u] = j0 + 64 * u < n ? Sop[(int64_t)p * n + j0 + 64 * u] : 0.0;
       }
 #pragma unroll
-    for (int u = 0; u < UP; ++u)
+    for (int q = 0; q < SUBFIN_SPW; ++q)
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p)
-        if (p < P && j0 + 64 * u < n) acc[p] = fma(sv[p][u], kv[u], acc[p]);
+      for (int u = 0; u < UP; ++u)
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p)
+          if (p < P && j0 + 64 * u < n) acc[q][p] = fma(sv[p][u], kv[q][u], acc[q][p]);
   }
 #pragma unroll
-  for (int p = 0; p < MAXP; ++p) {
-    if (p < P) {                                         // (wave-uniform: the unused sums are not reduced)
-      double x = acc[p];
-      for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
-      if (lane == 0) theta[s * P + p] = x;
+  for (int q = 0; q < SUBFIN_SPW; ++q)
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      if (p < P && s0 + q < S) {                         // (wave-uniform: the unused sums are not reduced)
+        double x = acc[q][p];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+        if (lane == 0) theta[(s0 + q) * P + p] = x;
+      }
     }
-  }
 }
 
 // The same product for parameter vectors (n = 5 / 9 conductivities per sample, the dataset loop's five- and nine-parameter forms):
@@ -77,11 +87,13 @@ __global__ __launch_bounds__(256) void subfin_avg_small_kernel(const double* __r
 int launch_subfin_avg(const double* Sop, int P, int n, const double* k, int64_t S, double* theta, hipStream_t st) {
   if (S == 0) return 0;
   if (P > MAXP) { set_error("subfin_avg: P > 16"); return FINROM_ERR_UNSUPPORTED; }
+  const auto wgs = [&](int spw) { return dim3((unsigned)((S + 4 * spw - 1) / (4 * spw))); };
   ScopedKernelTimer t(K_AVG, st);
   if (n <= SUBFIN_SMALL_N)
     hipLaunchKernelGGL(subfin_avg_small_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, Sop, P, n, k, S, theta);
   else
-    hipLaunchKernelGGL(subfin_avg_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, Sop, P, n, k, S, theta);
+    if (P <= 10) hipLaunchKernelGGL((subfin_avg_kernel<10, 4>), wgs(4), dim3(256), 0, st, Sop, P, n, k, S, theta);
+    else hipLaunchKernelGGL((subfin_avg_kernel<16, 2>), wgs(2), dim3(256), 0, st, Sop, P, n, k, S, theta);
   FR_HIP(hipGetLastError());
   return 0;
 }
