@@ -174,6 +174,36 @@ struct finrom_rom_s {
   int projection = FINROM_PROJECTION_DIRECT;
   hipStream_t side = nullptr;          // library-owned stream for the ROM half of finrom_solve_pairs / the error model of finrom_romml_grad
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // the FOM half of finrom_solve_pairs on a stream restricted to a SUBSET of the CUs (hipExtStreamCreateWithCUMask): the sweep's
+  // waves then share SIMDs with the projection on those CUs only, and run faster for being fewer.  cus < 0: per_se = -cus
+  // CUs in every shader engine (the mask's bit i is CU i / n_se of shader engine i % n_se -- measured: the first 32 c bits give the
+  // sweep the same speed as any 32 c' <= bits < 32 (c + 1), and bit patterns that fill whole engines starve the dispatcher)
+  hipStream_t fom_side = nullptr; hipEvent_t ev_join_fom = nullptr; int fom_side_cus = 0;
+  int ensure_fom_side(int cus) {
+    if (fom_side && fom_side_cus == cus) return 0;
+    if (call_captures() || any_capture()) { set_error("the FOM side stream cannot be created while a stream capture is open"); return FINROM_ERR_UNSUPPORTED; }
+    if (fom_side) { (void)hipStreamDestroy(fom_side); fom_side = nullptr; }
+    int dev = 0; hipDeviceProp_t pr;
+    FR_HIP(hipGetDevice(&dev));
+    FR_HIP(hipGetDeviceProperties(&pr, dev));
+    const int ncu = pr.multiProcessorCount;
+    const int want = cus;
+    if (cus < 0) cus = -cus * (ncu / 8);                 // (eight CUs per shader engine on gfx950)
+    if (cus < 1 || cus > ncu) { set_error("FINROM_FOM_CUS out of range"); return FINROM_ERR_ARG; }
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    const int mode = getenv("FINROM_FOM_CUS_MODE") != nullptr ? atoi(getenv("FINROM_FOM_CUS_MODE")) : 1;
+    for (int t = 0; t < cus; ++t) {
+      int b = (int)((int64_t)t * ncu / cus);                                     // mode 0: spread evenly over the bit array
+      if (mode == 1) b = t;                                                       // mode 1: the first `cus` bits
+      if (mode == 2) b = (t % 8) * (ncu / 8) + t / 8;                            // mode 2: round robin over eight blocks of ncu / 8 bits
+      if (mode == 3) b = (t % 8) * 32 + t / 8;                                    // mode 3: round robin over 32-bit words (one per XCD?)
+      mask[b >> 5] |= 1u << (b & 31);
+    }
+    FR_HIP(hipExtStreamCreateWithCUMask(&fom_side, (uint32_t)mask.size(), mask.data()));
+    if (!ev_join_fom) FR_HIP(hipEventCreateWithFlags(&ev_join_fom, hipEventDisableTiming));
+    fom_side_cus = want;
+    return 0;
+  }
   int ensure_side() {
     if (side) return 0;
     if (call_captures() || any_capture()) { set_error("the library's side stream cannot be created while a stream capture is open: run the call once before the capture"); return FINROM_ERR_UNSUPPORTED; }
@@ -1289,6 +1319,8 @@ void finrom_rom_destroy(finrom_rom_t h) {
   h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release(); h->ticket.release(); h->grad_ticket.release();
   h->part.release();
   if (h->side) defer_or_run([](void* s) { (void)hipStreamDestroy((hipStream_t)s); }, h->side);
+  if (h->fom_side) defer_or_run([](void* s) { (void)hipStreamDestroy((hipStream_t)s); }, h->fom_side);
+  if (h->ev_join_fom) defer_or_run([](void* e) { (void)hipEventDestroy((hipEvent_t)e); }, h->ev_join_fom);
   if (h->ev_fork) defer_or_run([](void* e) { (void)hipEventDestroy((hipEvent_t)e); }, h->ev_fork);
   if (h->ev_join) defer_or_run([](void* e) { (void)hipEventDestroy((hipEvent_t)e); }, h->ev_join);
   delete h;
@@ -1570,10 +1602,29 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   // Every workspace the two halves need is reserved BEFORE the fork: an allocation failure after it would return while the
   // side stream still writes the caller's outputs.  Any other failure after the fork joins the side stream first.
   const bool split = S <= fom_chunk_samples(fom->d, &fom->band);
+  // Round 4: beside the ONE-WAVE projection kernel (r <= 80, two 200-register waves per SIMD) the register band sweep (m <= 12, one
+  // 312-register wave per SIMD) runs on a stream masked to THREE CUs of every shader engine (96 of 256): what the projection loses is
+  // proportional to the CU-time it shares with sweep waves, and confined to fewer CUs the sweep's waves -- fewer at a time, less
+  // contention for HBM -- need less of it in total (256 CUs x 6.9 ms -> 96 x 15.3 ms; the sweep still ends long before the projection).
+  // Measured, headline: step 21.54 -> 20.92 ms; two CUs per engine make the sweep the longer half (22.4), four give 21.06.  NOT for the
+  // multi-wave projection kernels (r = 120: 49.7 -> 56.7 ms, their workgroups leave the confined sweep too few slots), the four-wave
+  // sweep (LDS-exclusive: no change) or the offline/online form (FOM-bound: 9.1 -> 14.3).  FINROM_FOM_CUS=<n> forces n CUs (0: off).
+  static const int env_fom_cus = getenv("FINROM_FOM_CUS") != nullptr ? atoi(getenv("FINROM_FOM_CUS")) : -1;
+  static const bool env_no_band2 = getenv("FINROM_NO_BAND") != nullptr;
+  int fom_cus = env_fom_cus;
+  if (fom_cus < 0)
+    fom_cus = (rom->projection == FINROM_PROJECTION_DIRECT && rom->d.NB <= 5 && fom->band.on && fom->band.NSP <= 14 && !env_no_band2 &&
+               w == nullptr && S >= 16384 && getenv("FINROM_PROJ_LDS") == nullptr) ? -3 : 0;
+  hipStream_t fst = st;
+  if (overlap && fom_cus != 0) {
+    if ((rc = rom->ensure_fom_side(fom_cus))) return rc;
+    fst = rom->fom_side;
+  }
   auto join = [&]() {
     if (overlap && hipEventRecord(rom->ev_join, side) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join, 0);
+    if (fst != st && hipEventRecord(rom->ev_join_fom, fst) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join_fom, 0);
   };
-  auto fail = [&](int code) { if (overlap) (void)hipStreamSynchronize(side); return code; };
+  auto fail = [&](int code) { if (overlap) (void)hipStreamSynchronize(side); if (fst != st) (void)hipStreamSynchronize(fst); return code; };
   if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 4))) return rc;          // (reserves the FOM workspace)
   // the sub-fin averages (bandwidth-bound, short) run BEFORE the fork, alone: beside the sweep they were starved (0.19 -> 0.39 ms
   // at the headline, 0.6 -> 5.8 ms at m = 20) and they head the ROM half's critical path
@@ -1581,9 +1632,10 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   if (overlap) {                          // the ROM half starts after the averages
     FR_HIP(hipEventRecord(rom->ev_fork, st));
     FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
+    if (fst != st) FR_HIP(hipStreamWaitEvent(fst, rom->ev_fork, 0));
   }
   if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return fail(rc);
-  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 3))) return fail(rc);
+  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, fst, 3))) return fail(rc);
   join();
   if (err && (rc = launch_sub(qoi, qoi_r, S * (int64_t)fom->d.n_obs, err, st))) return rc;
   if (tracing) {
