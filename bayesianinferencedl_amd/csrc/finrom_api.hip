@@ -180,7 +180,7 @@ struct finrom_rom_s {
   // sweep the same speed as any 32 c' <= bits < 32 (c + 1), and bit patterns that fill whole engines starve the dispatcher)
   hipStream_t fom_side = nullptr; hipEvent_t ev_join_fom = nullptr; int fom_side_cus = 0;
   int ensure_fom_side(int cus) {
-    if (fom_side && fom_side_cus == cus) return 0;
+    if (fom_side_cus == cus && (fom_side || cus != 0)) return 0;      // (made, or refused by the runtime once: do not ask again)
     if (call_captures() || any_capture()) { set_error("the FOM side stream cannot be created while a stream capture is open"); return FINROM_ERR_UNSUPPORTED; }
     if (fom_side) { (void)hipStreamDestroy(fom_side); fom_side = nullptr; }
     int dev = 0; hipDeviceProp_t pr;
@@ -199,7 +199,8 @@ struct finrom_rom_s {
       if (mode == 3) b = (t % 8) * 32 + t / 8;                                    // mode 3: round robin over 32-bit words (one per XCD?)
       mask[b >> 5] |= 1u << (b & 31);
     }
-    FR_HIP(hipExtStreamCreateWithCUMask(&fom_side, (uint32_t)mask.size(), mask.data()));
+    // (a runtime that refuses the mask is not an error of the call: the FOM half then stays on the caller's stream, as before)
+    if (hipExtStreamCreateWithCUMask(&fom_side, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); fom_side = nullptr; fom_side_cus = want; return 0; }
     if (!ev_join_fom) FR_HIP(hipEventCreateWithFlags(&ev_join_fom, hipEventDisableTiming));
     fom_side_cus = want;
     return 0;
@@ -1618,7 +1619,7 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
   hipStream_t fst = st;
   if (overlap && fom_cus != 0) {
     if ((rc = rom->ensure_fom_side(fom_cus))) return rc;
-    fst = rom->fom_side;
+    if (rom->fom_side) fst = rom->fom_side;
   }
   auto join = [&]() {
     if (overlap && hipEventRecord(rom->ev_join, side) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join, 0);
@@ -1635,7 +1636,13 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     if (fst != st) FR_HIP(hipStreamWaitEvent(fst, rom->ev_fork, 0));
   }
   if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return fail(rc);
-  if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, fst, 3))) return fail(rc);
+  // (experiment, FINROM_FOM_PREPASS_UNMASKED=1: pack + assembly on the caller's unmasked stream, only the sweep on the masked one)
+  static const bool env_pre_unmasked = getenv("FINROM_FOM_PREPASS_UNMASKED") != nullptr;
+  if (fst != st && split && env_pre_unmasked) {
+    if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return fail(rc);
+    if (hipEventRecord(rom->ev_join_fom, st) != hipSuccess || hipStreamWaitEvent(fst, rom->ev_join_fom, 0) != hipSuccess) return fail(FINROM_ERR_HIP);
+    if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, fst, 2))) return fail(rc);
+  } else if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, fst, 3))) return fail(rc);
   join();
   if (err && (rc = launch_sub(qoi, qoi_r, S * (int64_t)fom->d.n_obs, err, st))) return rc;
   if (tracing) {
