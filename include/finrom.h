@@ -426,11 +426,15 @@ int finrom_sampler_draw_seeded(finrom_sampler_t h, uint64_t seed, int64_t first_
                                double* xi_out, void* stream);
 
 /* ---- the dataset-loop body for S samples in one call ---------------------------------- *
- * (deep_learning/generate_fin_dataset.py:93-100):  FOM solve + QoI on the caller's stream;
+ * (deep_learning/generate_fin_dataset.py:93-100):  FOM solve + QoI on the caller's stream
+ * (large batches of the r <= 80 / m <= 12 pairing: on a library stream restricted to three CUs
+ * of every shader engine -- the HBM-bound sweep then shares fewer SIMDs with the projection,
+ * DESIGN.md 5; FINROM_FOM_CUS=0 keeps the caller's stream);
  * concurrently, on a stream owned by the library, theta = Sop x (sub-fin averages of the
  * field, or of the interpolated per-fin conductivities) and the LSPG reduced solve + QoI;
- * then err = qoi - qoi_r.  The two halves are independent and are joined with HIP events,
- * so the latency-bound sparse solve overlaps the MFMA-bound projection.
+ * then err = qoi - qoi_r.  The two halves are independent and are joined with HIP events
+ * on the caller's stream (every output is ready in stream order behind the call),
+ * so the HBM-bound sparse solve overlaps the MFMA-bound projection.
  * Sop: device [P x xdim] (P = the ROM's parameter count, xdim = the FOM's).  Optional
  * outputs (NULL to skip): w [S x n], w_r [S x r], theta [S x P], err [S x n_obs].
  * info [S] must be zero-initialised by the caller (bits are OR-ed in). */
