@@ -58,3 +58,18 @@ def test_bench_roofline_is_a_fraction_for_every_config(argv):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel"] in d["kernels_avg_ms"] and "model" in rf
     assert d["config"]["failed_samples"] == 0
     _flops_below_peak(d)
+
+
+def test_cu_masked_fom_stream_gives_the_same_outputs():
+    """Beside the one-wave projection kernel the FOM sweep of a large batch runs on a library stream masked to three CUs per
+    shader engine (finrom_solve_pairs).  Where the kernels run must not change what they compute: the gathered QoI pairs
+    of the masked default, of an unmasked run (FINROM_FOM_CUS=0) and of another mask (64 CUs) have the same checksum."""
+    def run(env):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "20000", "--steps", "2", "--warmup", "1",
+                            "--cpu-samples", "0", "--no-other", "--no-host-io", "--no-profile"], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    masked, plain, other = run({}), run({"FINROM_FOM_CUS": "0"}), run({"FINROM_FOM_CUS": "64"})
+    assert masked["config"]["failed_samples"] == 0
+    assert masked["gathered_sha256"] == plain["gathered_sha256"] == other["gathered_sha256"]
