@@ -168,7 +168,7 @@ struct finrom_fom_s {
 struct finrom_rom_s {
   RomDev d{};
   std::vector<void*> owned;
-  Scratch Ar, Br, theta, qtmp, vw, ticket, grad_ticket, part;
+  Scratch Ar, Br, theta, qtmp, vw, ticket, grad_ticket, part, ext;
   int g_npairs = 0; const int* g_pair_p = nullptr; const int* g_pair_i = nullptr; const double* g_Gt = nullptr;
   RomGramDev gram;                     // offline/online form (finrom_rom_set_gram); gram.h is filled at create
   int projection = FINROM_PROJECTION_DIRECT;
@@ -1232,6 +1232,80 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
     tvu.resize(tvu.size() + (size_t)4 * 4 * rp, 0.0);       // one k-step of padding for the prefetch
     kpat.resize(kpat.size() + 16, 0);                        // the scalar pipeline reads up to two k-steps ahead
     d.tvu_bytes = (int)std::min<size_t>(tvu.size() * sizeof(double), (size_t)0x7FFFFFF0);
+
+    // ---- the same k-steps GROUPED by their leading parameter (proj_main_grouped, NB <= 5) ----------------------------------
+    // A k-step whose rows carry {theta_d} or {1, theta_d} belongs to group d and is accumulated DIVIDED by theta_d: its slab is
+    // T_d (no arithmetic at all) or T_d + (1/theta_d) T_0 (one multiply-add per block); the accumulators are rescaled where the
+    // group changes -- by (theta_d / theta_e)^2 between groups d and e, by theta_d^2 after the last -- so that the sum is the
+    // one the ungrouped loop forms, up to rounding.  Everything else (rows that touch two parameters, merged leftovers) comes
+    // first, at scale 1, with the usual coefficients.  The per-sample scalars (1, theta, 1 / theta, the rescale factors) are
+    // one row of RomDev::ext, filled by rom_ext_kernel ahead of the projection kernel; the records name them by index.
+    d.n_ext = 0; d.nkg = 0; d.ext_final = 0; d.ext = nullptr;
+    if (NB <= 5 && getenv("FINROM_PROJ_UNGROUPED") == nullptr) {
+      struct GStep { int group; std::vector<int> pat; const int* rows; };
+      std::vector<GStep> gs;
+      for (const KStep& ks : ksteps) {
+        if (ks.rows[0] < 0 && ks.rows[1] < 0 && ks.rows[2] < 0 && ks.rows[3] < 0) continue;      // the padding k-steps of the list above
+        int group = 0;
+        std::vector<int> pat = ks.pat;
+        if (pat.size() == 1 && pat[0] != 0) group = pat[0];
+        else if (pat.size() == 2 && (pat[0] == 0) != (pat[1] == 0)) { group = pat[0] ? pat[0] : pat[1]; pat = {group, 0}; }
+        gs.push_back({group, pat, ks.rows});
+      }
+      std::stable_sort(gs.begin(), gs.end(), [](const GStep& x, const GStep& y) { return x.group < y.group; });
+      std::vector<int> groups;
+      for (const GStep& g : gs) if (g.group && (groups.empty() || groups.back() != g.group)) groups.push_back(g.group);
+      const int P = a->P, n_ext = 1 + 2 * P + (int)groups.size() + 1;
+      if (!groups.empty() && n_ext <= 64) {
+        // ext[0] = 1, ext[p] = theta_p, ext[P + p] = 1 / theta_p, then one factor per change of group; as (numerator, denominator, squared)
+        std::vector<int> def(3 * (size_t)n_ext, 0);
+        for (int pp = 1; pp <= P; ++pp) { def[3 * pp] = pp; def[3 * (P + pp) + 1] = pp; }
+        std::vector<int> factor_of(groups.size() + 1);
+        for (size_t g = 0; g <= groups.size(); ++g) {
+          const int e = 1 + 2 * P + (int)g;
+          def[3 * e] = g == 0 ? 0 : groups[g - 1]; def[3 * e + 1] = g == groups.size() ? 0 : groups[g]; def[3 * e + 2] = 1;
+          factor_of[g] = e;
+        }
+        std::vector<double> tvg; std::vector<int> kmg;
+        int slot = 0, prev = 0;
+        bool first = true;
+        for (const GStep& g : gs) {
+          const int nt = (int)g.pat.size();
+          int rec[8] = {slot, nt, 0, 0, 0, 0, 0, 0};
+          for (int t = 0; t < nt; ++t) rec[4 + t] = g.group ? (t == 0 ? 0 : P + g.group) : g.pat[t];
+          if (rec[4] == 0) rec[2] |= 1;                       // the first coefficient is 1: its rows are the slab as they are
+          if (g.group != prev && !first) {                   // (nothing to rescale in front of the very first k-step)
+            const size_t gi = std::find(groups.begin(), groups.end(), g.group) - groups.begin();
+            rec[2] |= 2; rec[3] = factor_of[gi];             // (from scale 1: (1 / theta_d)^2)
+          }
+          prev = g.group; first = false;
+          kmg.insert(kmg.end(), rec, rec + 8);
+          for (int t = 0; t < nt; ++t)
+            for (int q = 0; q < 4; ++q) {
+              const size_t base = tvg.size();
+              tvg.resize(base + rp, 0.0);
+              const int row = g.rows[q];
+              if (row < 0) continue;
+              for (int tt = a->row_ptr[row]; tt < a->row_ptr[row + 1]; ++tt)
+                if (a->term_p[tt] == g.pat[t]) for (int col = 0; col < r; ++col) tvg[base + col] += a->term_val[(size_t)tt * r + col];
+            }
+          slot += nt;
+        }
+        // zero k-steps fill the list up to a multiple of three (the loop rotates three slab buffers) and serve the pipeline's reads
+        // of the records / rows of the k-steps behind the last one
+        int nkg = (int)gs.size();
+        const int zslot = slot;
+        tvg.resize(tvg.size() + (size_t)4 * 4 * rp, 0.0);
+        while (nkg % 3) { int rec[8] = {zslot, 1, 1, 0, 0, 0, 0, 0}; kmg.insert(kmg.end(), rec, rec + 8); ++nkg; }
+        for (int k = 0; k < 8; ++k) { int rec[8] = {zslot, 1, 1, 0, 0, 0, 0, 0}; kmg.insert(kmg.end(), rec, rec + 8); }
+        d.nkg = nkg; d.n_ext = n_ext; d.ext_final = factor_of[groups.size()];
+        d.tvg_bytes = (int)std::min<size_t>(tvg.size() * sizeof(double), (size_t)0x7FFFFFF0);
+        int grc = up(h->owned, &d.tvg, tvg.data(), tvg.size());
+        if (!grc) grc = up(h->owned, &d.kmg, kmg.data(), kmg.size());
+        if (!grc) grc = up(h->owned, &d.ext_def, def.data(), def.size());
+        if (grc) { finrom_rom_destroy(h); return grc; }
+      }
+    }
   }
   // chunk images for the LDS-staged kernel: whole k-steps of one phase, <= 32 KiB, padded to 1 KiB
   std::vector<int> ch_nt, ch_nks, ch_off, ch_bytes;
@@ -1318,7 +1392,7 @@ void finrom_rom_destroy(finrom_rom_t h) {
   if (!h) return;
   for (void* p : h->owned) dev_free(p);
   h->Ar.release(); h->Br.release(); h->theta.release(); h->qtmp.release(); h->vw.release(); h->ticket.release(); h->grad_ticket.release();
-  h->part.release();
+  h->part.release(); h->ext.release();
   if (h->side) defer_or_run([](void* s) { (void)hipStreamDestroy((hipStream_t)s); }, h->side);
   if (h->fom_side) defer_or_run([](void* s) { (void)hipStreamDestroy((hipStream_t)s); }, h->fom_side);
   if (h->ev_join_fom) defer_or_run([](void* e) { (void)hipEventDestroy((hipEvent_t)e); }, h->ev_join_fom);
@@ -1387,7 +1461,13 @@ static int rom_project(finrom_rom_t h, const double* theta, int64_t S, int facto
   if (h->projection == FINROM_PROJECTION_GRAM)
     return launch_rom_gram(h->d, h->gram, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r);
   if (h->ticket.reserve(4096 * sizeof(int))) return FINROM_ERR_NOMEM;
-  return launch_rom_proj(h->d, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r, (int*)h->ticket.p);
+  RomDev d = h->d;
+  d.ext = nullptr;
+  if (d.nkg > 0 && S > 0 && !rom_splitk_applies(d, S)) {      // the grouped main loop: room for the samples' scalars
+    if (int rc = h->ext.reserve((size_t)S * d.n_ext * sizeof(double))) return rc;
+    d.ext = (double*)h->ext.p;
+  }
+  return launch_rom_proj(d, theta, S, (double*)h->Ar.p, (double*)h->Br.p, factor, info, st, w_r, qoi_r, (int*)h->ticket.p);
 }
 
 int finrom_rom_solve(finrom_rom_t h, const double* theta, int64_t S, double* w_r, double* qoi_r, double* A_r,

@@ -100,6 +100,15 @@ struct RomDev {
                                         // term-count group holds an even number of k-steps, padded with a zero k-step)
   int uend[4];                          // uend[t] = number of k-steps with more than t terms (uend[0] = nku)
   const int* kmeta;                     // [(nku + 8) * 8] per k-step: first slot, term count, 2 x padding, theta indices of its 4 slots
+  // the pattern-uniform k-steps grouped by their leading parameter and accumulated divided by it (proj_main_grouped; built in
+  // finrom_rom_create, where the form is described): records {first slot, terms, flags (1: the first coefficient is 1, 2: rescale
+  // the accumulators first), ext index of that factor, ext indices of the coefficients}
+  const double* tvg; int tvg_bytes;
+  const int* kmg;                       // [(nkg + 8) * 8]
+  int nkg;                              // multiple of 3; 0: no grouped form (nothing to group, too many parameters, NB > 5)
+  int n_ext, ext_final;                 // per-sample scalars (<= 64); ext index of the factor behind the last k-step
+  const int* ext_def;                   // [n_ext * 3] ext[l] = (theta'[a] / theta'[b]) ^ (1 + sq), theta'[0] = 1
+  double* ext;                          // [S x n_ext] workspace of the CALL (set by rom_project; nullptr: the ungrouped loop)
   const double* tv;                     // [(nslots + 4) * 4 * rp]  padded r-vectors, slot-major
   const int* pidx;                      // [(nslots + 4) * 4]       theta index of each r-vector (0 = constant 1)
   // rows with a non-zero load F (root nodes), same slot format with a runtime term count

@@ -326,6 +326,116 @@ __device__ __forceinline__ void proj_main_uniform(const RomDev& p, const int* __
 }
 
 // ---------------------------------------------------------------------------------------
+// The same loop on the GROUPED tables (RomDev::tvg / kmg, built in finrom_rom_create): most k-steps then need no vector
+// arithmetic at all.  A row of psi in the interior of sub-domain d is theta_d T; accumulated DIVIDED by theta_d the slab is the
+// table's rows as they are, and the buffer loads deliver the MFMA operands directly; rows on the Robin boundary of d add one
+// multiply-add per block (T_d + (1 / theta_d) T_0).  Where the group changes the accumulators are multiplied by the ratio of the
+// two scales squared (NT x 4 multiplies behind a drain: ten times per sample at nine sub-domains), after the last k-step by the
+// last scale squared; the scalars come from the sample's row of RomDev::ext (rom_ext_kernel), read with scalar loads like theta
+// above.  Measured at r = 80, 100k samples, beside the FOM sweep: 21.16 -> 20.04 ms per launch (the multiplies merely skipped in
+// the loop above, garbage results: 20.94 -> 20.38).
+// Three slab buffers rotate (loop unrolled three times; the host pads the list to a multiple of three): k-step ks multiplies x0,
+// k-step ks + 1 is completed in place in x1 (gap 0), the first-term rows of k-step ks + 2 land in x2, its further terms in e.
+template <int N>
+__device__ __forceinline__ void mfma_fence(d4 (&acc)[N]) {      // VALU wrote the accumulators: nothing that reads them may move above, and the MFMA that follows keeps its wait states
+#pragma unroll
+  for (int t = 0; t < N; ++t) {
+    if (t == 0) asm volatile("s_nop 7" : "+v"(acc[t]));
+    else asm volatile("" : "+v"(acc[t]));
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void proj_main_grouped(const RomDev& p, const int* __restrict__ kmg_g, const double* __restrict__ ext_g,
+                                                  int q, int c, d4 (&acc)[NB * (NB + 1) / 2]) {
+  constexpr int NTL = NB * (NB + 1) / 2;
+  typedef const i4 __attribute__((address_space(4)))* c_i4_p;
+  const c_i4_p kmg = (c_i4_p)(unsigned long long)kmg_g;
+  const c_f64_p ext_s = (c_f64_p)(unsigned long long)ext_g;
+  const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.tvg), 0, p.tvg_bytes, 0x00020000);
+  const int voff = (q * p.rp + c) * 8;
+  const int rowb = 4 * p.rp * 8;
+  auto ldt = [&](int slot, auto bc) -> double {
+    constexpr int b = decltype(bc)::value;
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(tres, voff + 128 * b, slot * rowb, 0));
+  };
+  auto load_first = [&](double (&x)[NB], int slot) { sfor<0, NB>([&](auto bc) { x[decltype(bc)::value] = ldt(slot, bc); }); };
+  auto load_extra = [&](double (&e)[ROM_MAX_NT - 1][NB], auto tc, int slot, int nt) {
+    constexpr int t = decltype(tc)::value;
+    if (t < nt) {
+      asm volatile("" ::: "memory");                     // (keeps the branch a branch)
+      sfor<0, NB>([&](auto bc) { e[t - 1][decltype(bc)::value] = ldt(slot + t, bc); });
+    }
+  };
+  auto finish = [&](double (&x)[NB], const double (&e)[ROM_MAX_NT - 1][NB], const double (&cf)[ROM_MAX_NT], int nt, int flags) {
+    if (!(flags & 1)) {
+      asm volatile("" ::: "memory");
+      sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; x[b] = cf[0] * x[b]; });
+    }
+    sfor<1, ROM_MAX_NT>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if (t < nt) {
+        asm volatile("" ::: "memory");
+        sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; x[b] = fma(cf[t], e[t - 1][b], x[b]); });
+      }
+    });
+  };
+  auto rescale = [&](double f) {
+    mfma_drain(acc);
+    sfor<0, NTL>([&](auto ic) { constexpr int i = decltype(ic)::value; acc[i] = acc[i] * f; });
+    mfma_fence(acc);
+  };
+  double xa[NB], xb[NB], xc[NB], e[ROM_MAX_NT - 1][NB], cf1[ROM_MAX_NT], f1;
+  sfor<0, ROM_MAX_NT - 1>([&](auto tc) { sfor<0, NB>([&](auto bc) { e[decltype(tc)::value][decltype(bc)::value] = 0.0; }); });
+  // prologue: k-step 0 complete in xa, the rows of k-step 1 on their way into xb / e, the scalars of k-steps 1 and 2
+  i4 m0 = kmg[0], k0 = kmg[1];
+  load_first(xa, m0[0]);
+  sfor<1, ROM_MAX_NT>([&](auto tc) { load_extra(e, tc, m0[0], m0[1]); });
+  sfor<0, ROM_MAX_NT>([&](auto tc) { cf1[decltype(tc)::value] = ext_s[k0[decltype(tc)::value]]; });
+  finish(xa, e, cf1, m0[1], m0[2]);
+  i4 m1 = kmg[2], k1 = kmg[3];
+  load_first(xb, m1[0]);
+  sfor<1, ROM_MAX_NT>([&](auto tc) { load_extra(e, tc, m1[0], m1[1]); });
+  sfor<0, ROM_MAX_NT>([&](auto tc) { cf1[decltype(tc)::value] = ext_s[k1[decltype(tc)::value]]; });
+  f1 = ext_s[m1[3]];
+  int nt1 = m1[1], fl1 = m1[2];
+  i4 m2 = kmg[4], k2 = kmg[5];
+  asm volatile("s_nop 7" ::: "memory");                  // xa may have been written by VALU just now: VALU -> MFMA operand wait states
+
+  auto step = [&](double (&x0)[NB], double (&x1)[NB], double (&x2)[NB], int ks) {
+    double cf2[ROM_MAX_NT], f2;
+    i4 m3, k3;
+    sfor<0, NTL>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int ti = tile_ti<NB>(i), tj = tile_tj<NB>(i);
+      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(x0[ti]), "v"(x0[tj]));
+      constexpr int last = NTL - 1;
+      if constexpr (i == 0) finish(x1, e, cf1, nt1, fl1);
+      if constexpr (i == (1 < last ? 1 : last)) load_first(x2, m2[0]);
+      if constexpr (i == (2 < last ? 2 : last)) load_extra(e, std::integral_constant<int, 1>{}, m2[0], m2[1]);
+      if constexpr (i == (3 < last ? 3 : last)) load_extra(e, std::integral_constant<int, 2>{}, m2[0], m2[1]);
+      if constexpr (i == (4 < last ? 4 : last)) load_extra(e, std::integral_constant<int, 3>{}, m2[0], m2[1]);
+      if constexpr (i == (5 < last ? 5 : last)) {
+        sfor<0, ROM_MAX_NT>([&](auto tc) { cf2[decltype(tc)::value] = ext_s[k2[decltype(tc)::value]]; });
+        f2 = ext_s[m2[3]];
+        m3 = kmg[2 * (ks + 3)]; k3 = kmg[2 * (ks + 3) + 1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (fl1 & 2) rescale(f1);                            // k-step ks + 1 opens a group: its scale from here on
+    sfor<0, ROM_MAX_NT>([&](auto tc) { cf1[decltype(tc)::value] = cf2[decltype(tc)::value]; });
+    f1 = f2; nt1 = m2[1]; fl1 = m2[2]; m2 = m3; k2 = k3;
+  };
+#pragma unroll 1
+  for (int ks = 0; ks < p.nkg; ks += 3) {
+    step(xa, xb, xc, ks);
+    step(xb, xc, xa, ks + 1);
+    step(xc, xa, xb, ks + 2);
+  }
+  if (p.ext_final) rescale(ext_s[p.ext_final]);
+}
+
+// ---------------------------------------------------------------------------------------
 // Main loop of the multi-wave kernels (NW waves = one workgroup = one sample, r > 96) on the same pattern-uniform tables.
 // Wave W owns the blocks b = W, W + NW, .. of the slab (builds them: 1/NW of the table loads and multiply-adds) and the
 // tiles idx = W, W + NW, .. of the block triangle; the slab travels through LDS.  Same interleaving as above -- everything
@@ -852,13 +962,15 @@ __device__ __forceinline__ int fused_solve_sw(const RomDev& p, d4 (&acc)[NB * (N
   return bad;
 }
 
-template <int NB, int NW, int W, bool SK = false>
+template <int NB, int NW, int W, bool SK = false, bool GR = false>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                               int* __restrict__ info, double* __restrict__ w_r = nullptr,
                                               double* __restrict__ qoi_r = nullptr, double* slab = nullptr,
                                               const double* __restrict__ theta_s = nullptr, const int* __restrict__ kpat = nullptr,
-                                              int kpart = 0, int kparts = 1, const RomGradArgs* ga = nullptr, double* mt_lds = nullptr) {
+                                              int kpart = 0, int kparts = 1, const RomGradArgs* ga = nullptr, double* mt_lds = nullptr,
+                                              const double* __restrict__ ext_s = nullptr) {
+  // GR with ext_s: the grouped main loop -- kpat is then RomDev::kmg and ext_s the sample's row of RomDev::ext
   // kparts > 1 (NW == 1, small batches): the sample's k-steps are split over the kparts waves of the workgroup, the partial
   // block triangles are summed through LDS (`slab`) in a fixed order and wave 0 alone runs the epilogue
   constexpr int NTL = (NB * (NB + 1) / 2 + NW - 1) / NW;
@@ -875,7 +987,10 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     // copy of the kernel arguments in scratch memory once the fused epilogue was added)
     proj_main_uniform_mw<NB, NW, W>(p, kpat, theta_s, q, c, lane, slab, acc);
   } else if ((p.clock_probe & 15) != 3) {      // (bits 4 / 5: timing experiments without table loads / without scalar loads)
-    if constexpr (NW == 1) {
+    if constexpr (NW == 1 && GR) {
+      if (ext_s != nullptr) proj_main_grouped<NB>(p, kpat, ext_s, q, c, acc);
+      else proj_main_uniform<NB>(p, kpat, theta_s, q, c, acc, p.nku);
+    } else if constexpr (NW == 1) {
       const int per = ((p.nku + kparts - 1) / kparts + 1) / 2 * 2, k0 = kpart * per;
       const int cnt = kparts == 1 ? p.nku : (k0 >= p.nku ? 0 : (p.nku - k0 < per ? p.nku - k0 : per));
       if (cnt > 0) proj_main_uniform<NB>(p, kpat + 8 * k0, theta_s, q, c, acc, cnt);      // kpat = RomDev::kmeta as a kernel parameter  // (FINROM_CLOCK_PROBE=3: the per-lane-theta loop below, for A/B timing)
@@ -1122,7 +1237,7 @@ __device__ __forceinline__ void rom_proj_entry_splitk(RomDev p, const double* __
 
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
 // workgroup is max(4, NW) waves = max(4, NW)/NW samples.
-template <int NB, int NW>
+template <int NB, int NW, bool GR = false>
 __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                        int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
@@ -1147,8 +1262,16 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
                                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ta));     // provably in SGPRs
   const double* theta_u = theta_s;
   if constexpr (NW == 1) {
-    rom_proj_body<NB, 1, 0>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r, nullptr, theta_s, kpat, 0, 1, nullptr,
-                            NB <= 5 ? mt_sw + wave * ROM_SW_LDS : nullptr);
+    const double* ext_s = nullptr;
+    if constexpr (GR) {
+      if (p.ext != nullptr) {
+        const unsigned long long ea = (unsigned long long)(p.ext + ((int64_t)blockIdx.x * WPB + wave) * p.n_ext);
+        ext_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ea >> 32)) << 32) |
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ea));
+      }
+    }
+    rom_proj_body<NB, 1, 0, false, GR>(p, thw, s, lane, Ar, Br, factor, info, w_r, qoi_r, nullptr, theta_s, kpat, 0, 1, nullptr,
+                                       NB <= 5 ? mt_sw + wave * ROM_SW_LDS : nullptr, ext_s);
   } else if constexpr (NW == 4) {
     switch (wave % 4) {
       case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;

@@ -15,7 +15,22 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(100))) void 
                                                                  int* __restrict__ info, double* __restrict__ w_r,
                                                                  double* __restrict__ qoi_r, const int* __restrict__ kpat) {
   // (kpat = p.kpat as a __restrict__ kernel parameter of its own: only then are its reads scalar loads)
-  rom_proj_entry<NB, 1>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
+  // (with p.ext: the grouped main loop -- kpat is then p.kmg)
+  rom_proj_entry<NB, 1, true>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
+}
+
+// the samples' scalars for the grouped main loop (RomDev::ext_def): ext[s][l] = (theta'[a_l] / theta'[b_l]) ^ (1 + sq_l), theta'[0] = 1
+__global__ __launch_bounds__(256) void rom_ext_kernel(const double* __restrict__ theta, int P, int64_t S, const int* __restrict__ def,
+                                                      int n_ext, double* __restrict__ ext) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= S * n_ext) return;
+  const int64_t s = i / n_ext;
+  const int l = (int)(i - s * n_ext);
+  const int a = def[3 * l], b = def[3 * l + 1];
+  const double num = a ? theta[s * P + a - 1] : 1.0, den = b ? theta[s * P + b - 1] : 1.0;
+  double v = num / den;
+  if (def[3 * l + 2]) v *= v;
+  ext[i] = v;
 }
 
 // small batches: the sample's k-steps split over four waves (rom_proj_entry_splitk)
@@ -59,9 +74,12 @@ int launch_rom_proj_single(const RomDev& p, const double* theta, int64_t S, doub
                            hipStream_t st, double* w_r, double* qoi_r, int* /*cu_ticket: unused (stagger experiment)*/) {
   const dim3 grid((unsigned)((S + 3) / 4)), block(256);
   static const size_t pad_lds = getenv("FINROM_PROJ_PAD_LDS") != nullptr ? (size_t)atoi(getenv("FINROM_PROJ_PAD_LDS")) : 0;      // occupancy experiments
+  if (p.ext != nullptr)
+    hipLaunchKernelGGL(rom_ext_kernel, dim3((unsigned)((S * p.n_ext + 255) / 256)), dim3(256), 0, st, theta, p.P, S, p.ext_def, p.n_ext, p.ext);
+  const int* kp = p.ext != nullptr ? p.kmg : p.kmeta;
   switch (p.NB) {
 #define FR_ONE(N) case N: if (pad_lds > 65536) (void)hipFuncSetAttribute((const void*)rom_proj_single_kernel<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad_lds); \
-                       hipLaunchKernelGGL(rom_proj_single_kernel<N>, grid, block, pad_lds, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta); break;
+                       hipLaunchKernelGGL(rom_proj_single_kernel<N>, grid, block, pad_lds, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kp); break;
     FR_ONE(1) FR_ONE(2) FR_ONE(3) FR_ONE(4) FR_ONE(5)
 #undef FR_ONE
     default: set_error("rom_proj_single: basis size > 80"); return FINROM_ERR_UNSUPPORTED;

@@ -192,7 +192,9 @@ def test_rom_gradient_batched_contraction(problems, spaces, m, r, S):
     assert (big["info"] == 0).all()
     small = [rom.grad_reduced_batch(None, theta=TH[i:i + 7]) for i in range(0, S, 7)]
     g_small = np.concatenate([x["g_theta"] for x in small]); J_small = np.concatenate([x["J"] for x in small])
-    assert rel(big["g_theta"], g_small) < 1e-9 and np.max(np.abs(big["J"] - J_small) / J_small) < 1e-12
+    # (two kernels, two summation orders for A_r -- the batch kernel accumulates the k-steps grouped by sub-domain, the split-K
+    # kernel of the small batches in table order: J agrees to the conditioning of A_r times the rounding unit)
+    assert rel(big["g_theta"], g_small) < 1e-9 and np.max(np.abs(big["J"] - J_small) / J_small) < 1e-11
     # per-sample observations through the batched path
     D = rng.uniform(0.1, 1.0, (S, 9))
     res2 = rom._rom.grad(TH, D)
