@@ -989,7 +989,7 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
   } else if ((p.clock_probe & 15) != 3) {      // (bits 4 / 5: timing experiments without table loads / without scalar loads)
     if constexpr (NW == 1 && GR) {
       if (ext_s != nullptr) proj_main_grouped<NB>(p, kpat, ext_s, q, c, acc);
-      else proj_main_uniform<NB>(p, kpat, theta_s, q, c, acc, p.nku);
+      else proj_main_uniform<NB>(p, p.ext != nullptr ? p.kmeta : kpat, theta_s, q, c, acc, p.nku);      // (kpat is RomDev::kmg when the launch is a grouped one)
     } else if constexpr (NW == 1) {
       const int per = ((p.nku + kparts - 1) / kparts + 1) / 2 * 2, k0 = kpart * per;
       const int cnt = kparts == 1 ? p.nku : (k0 >= p.nku ? 0 : (p.nku - k0 < per ? p.nku - k0 : per));
@@ -1264,7 +1264,11 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
   if constexpr (NW == 1) {
     const double* ext_s = nullptr;
     if constexpr (GR) {
-      if (p.ext != nullptr) {
+      // (the grouped form divides by the conductivities: a sample with a zero, subnormal, huge or non-finite one takes the
+      // ungrouped loop -- same sums as a handle without the grouped tables)
+      const double tl = lane < p.P ? theta[s * p.P + lane] : 1.0;
+      const bool plain = __ballot(!(__builtin_fabs(tl) > 1e-100 && __builtin_fabs(tl) < 1e100)) == 0;
+      if (p.ext != nullptr && plain) {
         const unsigned long long ea = (unsigned long long)(p.ext + ((int64_t)blockIdx.x * WPB + wave) * p.n_ext);
         ext_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ea >> 32)) << 32) |
                                 (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ea));

@@ -175,6 +175,54 @@ def test_scalar_call_surface(problems, spaces):
     assert rel(solver.forward_five_param(k5)[0].vector()[:], fo.forward_five_param(k5)) < TOL
 
 
+@pytest.mark.parametrize("m,r", [(12, 80), (12, 33), (4, 16)])
+def test_grouped_projection_against_the_ungrouped_loop_and_the_oracle(problems, spaces, m, r, monkeypatch):
+    """The one-wave projection kernel (r <= 80) accumulates psi^T psi grouped by sub-domain, each group divided by its
+    conductivity, and rescales the accumulators where the group changes (rom_proj_device.h::proj_main_grouped; reference
+    rom/averaged_affine_ROM.py:291-297 forms psi = A(theta) Phi and the product).  Same sums up to rounding: against a handle
+    created with FINROM_PROJ_UNGROUPED=1 (table order, every row multiplied by its conductivity), against the oracle, over the
+    dataset's two decades of conductivities; a sample whose conductivities cannot be divided by (zero, subnormal, huge, NaN) takes the ungrouped
+    loop inside the same launch -- bit for bit what the ungrouped handle gives, flags included."""
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    prob = problems(m); V = spaces(m)
+    phi = oracle_basis(prob, r)
+    ro = O.AffineROMOracle(prob, phi)
+    rom_g = AffineROMFin(V, None, phi)
+    monkeypatch.setenv("FINROM_PROJ_UNGROUPED", "1")
+    rom_u = AffineROMFin(V, None, phi)
+    monkeypatch.delenv("FINROM_PROJ_UNGROUPED")
+    rng = np.random.default_rng(23)
+    S = 301                                                # (> 64: the batch kernel; a ragged last workgroup)
+    TH = np.exp(rng.uniform(np.log(0.1), np.log(10.0), (S, 9)))      # (the dataset's range, generate_fin_dataset.py:75)
+    odd = {5: 0.0, 17: 1e-300, 40: 1e200, 77: np.nan, 130: -0.0, 300: np.inf}
+    for i, v in odd.items():
+        TH[i, i % 9] = v
+    TH[200, 3] = -2.5                                      # a negative conductivity divides like any other: grouped
+    g = rom_g._rom.solve(TH, want_state=True)
+    u = rom_u._rom.solve(TH, want_state=True)
+    assert np.array_equal(g["info"], u["info"])
+    plain = np.array([i not in odd for i in range(S)])
+    assert (g["info"][plain & (np.arange(S) != 200)] == 0).all()
+    for key in ("A_r", "B_r", "w_r", "qoi_r"):
+        for i in odd:                                      # the ungrouped loop, in the same launch
+            assert np.array_equal(g[key][i], u[key][i], equal_nan=True), (key, i)
+    ok = plain & (g["info"] == 0)
+    scale = np.abs(u["A_r"][ok]).max(axis=(1, 2), keepdims=True)
+    assert not np.array_equal(g["A_r"][ok], u["A_r"][ok]), "the grouped loop did not run"
+    assert np.max(np.abs(g["A_r"][ok] - u["A_r"][ok]) / scale) < 2e-13
+    assert np.allclose(g["qoi_r"][ok], u["qoi_r"][ok], rtol=1e-7, atol=1e-10)
+    for i in (0, 1, 150, 299):
+        w_r, A_r, B_r, psi = ro.forward_nine_param_reduced(TH[i], return_parts=True)
+        assert np.max(np.abs(g["A_r"][i] - A_r)) < 1e-12 * np.abs(A_r).max()
+        assert rel(g["qoi_r"][i], ro.B_obs_phi @ w_r) < 1e-7
+    # the QoI-only form (what finrom_solve_pairs launches: factorisation and substitutions inside the kernel)
+    gq = rom_g._rom.solve(TH, want_w=False); uq = rom_u._rom.solve(TH, want_w=False)
+    assert np.array_equal(gq["info"], uq["info"])
+    assert np.allclose(gq["qoi_r"][ok], uq["qoi_r"][ok], rtol=1e-7, atol=1e-10)
+    for i in odd:
+        assert np.array_equal(gq["qoi_r"][i], uq["qoi_r"][i], equal_nan=True), i
+
+
 @pytest.mark.parametrize("m,r,S", [(12, 80, 200), (12, 120, 70), (12, 33, 65), (4, 150, 64)])
 def test_rom_gradient_batched_contraction(problems, spaces, m, r, S):
     """Batches of >= 64 samples contract v_r^T G_pi w_r on the matrix cores (rom_grad_contract_kernel, 16 samples per wave);
