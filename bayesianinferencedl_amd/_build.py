@@ -11,7 +11,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libfinrom_hip.so")
-SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_wide.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip", "hmc_kernels.hip", "comm.hip"]
+SOURCES = ["finrom_api.hip", "fom_kernels.hip", "fom_band.hip", "fom_band_wide.hip", "fom_band_adjoint.hip", "rom_kernels.hip", "rom_proj_wide.hip", "rom_proj_half.hip", "rom_proj_single.hip", "rom_onesample.hip", "rom_gram.hip", "util_kernels.hip", "mlp_kernels.hip", "hmc_kernels.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, h) for h in ("finrom_core.h", "finrom_internal.h", "rom_proj_device.h", "fom_band_device.h", "mlp_device.h")] + [os.path.join(ROOT, "include", "finrom.h")]
 
 

@@ -145,6 +145,9 @@ int launch_rom_chol_blocked(const RomDev& p, double* Ar, int64_t S, int* info, h
 int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info, hipStream_t st,
                     double* w_r = nullptr, double* qoi_r = nullptr, int* cu_ticket = nullptr);
 constexpr int ROM_SPLITK_MAX_S = 64;      // batches up to this size take the split-K projection kernel (r = 49..96)
+// (r mod 16 in 1..8, NB >= 7: the HalfCover form of the multi-wave kernels, rom_proj_half.hip)
+int launch_rom_proj_half(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
+                         hipStream_t st, double* w_r, double* qoi_r);
 int launch_rom_proj_wide(const RomDev& p, const double* theta, int64_t S, double* Ar, double* Br, int factor, int* info,
                          hipStream_t st, double* w_r, double* qoi_r);
 bool rom_splitk_applies(const RomDev& p, int64_t S);

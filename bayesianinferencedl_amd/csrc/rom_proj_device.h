@@ -462,7 +462,108 @@ template <int NB, int NW> struct SlabOwner {
   static constexpr int block(int w, int j) { for (int b = 0; b < NB; ++b) if (owner(b) == w && j-- == 0) return b; return 0; }
 };
 
+// ---------------------------------------------------------------------------------------
+// Bases whose last 16-column block is at most half full (r mod 16 in 1..8: r = 120, 200): the block triangle pays for the empty
+// half in every tile of its last column and, like every basis, for the redundant half of every diagonal tile.  In units of 8
+// columns the last block is ONE unit u_last; the MFMA does not care which 16 columns sit on its two sides, so (HF = true):
+//   * tile (i, NB-1), i < NB-1, becomes  block i  x  [u_last | unit 2i]: its left half is what it was (block i x u_last), its
+//     right half is block i x unit 2i = the left half of the DIAGONAL tile (i, i), including that tile's lower-left block;
+//   * what is then missing of the diagonal tiles are the 8 x 8 blocks (2i+1, 2i+1) and (u_last, u_last): two of them per
+//     tile  [a | b] x [a | b]  -- so only every second diagonal slot issues an MFMA at all (NB / 2 of them stay empty, chosen
+//     from the waves that own the most tiles: r = 120: 36 -> 32 MFMAs per k-step, 9 -> 8 per wave; r = 200: 91 -> 85, the three
+//     waves that had 12 go to 11).
+// Slots keep their owners (tile idx in wave idx % NW, as the epilogues expect); behind the main loop mw_half_fixup moves the
+// pieces through LDS into the aligned tiles (the diagonal tile's upper-right block is its lower-left one read transposed).
+// The slab in LDS is [block][row q][16 columns]: an operand of two arbitrary units is one LDS read with a per-lane offset.
+template <int NB, int NW> struct HalfCover {
+  static constexpr int NT = NB * (NB + 1) / 2;
+  static constexpr int diag_idx(int i) { return i * NB - (i * (i - 1)) / 2; }
+  static constexpr int loop_unit(int i) { return i == NB - 1 ? 2 * NB - 2 : 2 * i + 1; }      // the unit whose square tile (i, i) still needs
+  struct Plan { int empty[NB]; int partner[NB]; };       // partner: of an empty slot its host, of a host the slot whose block it carries (-1: none)
+  static constexpr Plan make() {
+    Plan pl{};
+    int load[NW] = {};
+    for (int w = 0; w < NW; ++w) load[w] = (NT - w + NW - 1) / NW;
+    for (int i = 0; i < NB; ++i) { pl.empty[i] = 0; pl.partner[i] = -1; }
+    for (int e = 0; e < NB / 2; ++e) {
+      int best = -1;
+      for (int i = 0; i < NB; ++i)
+        if (!pl.empty[i] && (best < 0 || load[diag_idx(i) % NW] > load[diag_idx(best) % NW])) best = i;
+      pl.empty[best] = 1; --load[diag_idx(best) % NW];
+    }
+    int h = 0;
+    for (int i = 0; i < NB; ++i)
+      if (pl.empty[i]) { while (pl.empty[h] || pl.partner[h] >= 0) ++h; pl.partner[i] = h; pl.partner[h] = i; }
+    return pl;
+  }
+  static constexpr Plan plan = make();
+  static constexpr bool is_t1(int idx) { return tile_ti<NB>(idx) < NB - 1 && tile_tj<NB>(idx) == NB - 1; }
+  static constexpr bool is_diag(int idx) { return tile_ti<NB>(idx) == tile_tj<NB>(idx); }
+  static constexpr bool is_host(int idx) { return is_diag(idx) && !plan.empty[tile_ti<NB>(idx)]; }
+  static constexpr bool is_empty(int idx) { return is_diag(idx) && plan.empty[tile_ti<NB>(idx)]; }
+  static constexpr bool irregular(int idx) { return is_t1(idx) || is_host(idx); }
+  static constexpr int irr_count(int w) { int n = 0; for (int idx = w; idx < NT; idx += NW) n += irregular(idx); return n; }
+  static constexpr int irr_of_slot(int w, int i) { int n = 0; for (int idx = w; idx < w + i * NW; idx += NW) n += irregular(idx); return n; }
+  static constexpr int slot_of_irr(int w, int k) { int i = 0; for (int idx = w; idx < NT; idx += NW, ++i) if (irregular(idx) && k-- == 0) return i; return 0; }
+  // the two units of irregular operand k of wave w: lanes c < 8 / c >= 8
+  static constexpr int irr_x(int w, int k) { const int idx = w + slot_of_irr(w, k) * NW; return is_t1(idx) ? 2 * NB - 2 : loop_unit(tile_ti<NB>(idx)); }
+  static constexpr int irr_y(int w, int k) {
+    const int idx = w + slot_of_irr(w, k) * NW, ti = tile_ti<NB>(idx);
+    if (is_t1(idx)) return 2 * ti;
+    return plan.partner[ti] >= 0 ? loop_unit(plan.partner[ti]) : loop_unit(ti);
+  }
+  static constexpr int mfmas(int w) { int n = 0; for (int idx = w; idx < NT; idx += NW) n += !is_empty(idx); return n; }
+  static constexpr int lds_doubles() { return (NB - 1) * 128 + NB * 64; }
+};
+
+// the pieces of the diagonal tiles from where the HF main loop left them into the aligned tiles (all waves of the sample call it;
+// lds: the slab buffers, free behind the loop's last barrier)
 template <int NB, int NW, int W>
+__device__ __forceinline__ void mw_half_fixup(d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW], double* lds, int lane) {
+  using HC = HalfCover<NB, NW>;
+  constexpr int NT = NB * (NB + 1) / 2, MINE = (NT - W + NW - 1) / NW;
+  const int q = lane >> 4, c = lane & 15;
+  double* t1h = lds;                                     // [NB - 1][16 rows][8]: block i x unit 2i
+  double* loops = lds + (NB - 1) * 128;                  // [NB][8][8]: the square of loop_unit(i)
+  sfor<0, MINE>([&](auto ic) {
+    constexpr int i = decltype(ic)::value, idx = W + i * NW, ti = tile_ti<NB>(idx);
+    if constexpr (HC::is_t1(idx)) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (c >= 8) { t1h[ti * 128 + (q + 4 * g) * 8 + (c - 8)] = acc[i][g]; acc[i][g] = 0.0; }      // what stays is the aligned tile (ti, NB - 1)
+      }
+    } else if constexpr (HC::is_host(idx)) {
+      constexpr int pt = HC::plan.partner[ti];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        if (c < 8) loops[ti * 64 + (q + 4 * g) * 8 + c] = acc[i][g];
+        if constexpr (pt >= 0) { if (c >= 8) loops[pt * 64 + (q + 4 * g) * 8 + (c - 8)] = acc[i][g + 2]; }
+      }
+    }
+  });
+  __syncthreads();
+  sfor<0, MINE>([&](auto ic) {
+    constexpr int i = decltype(ic)::value, idx = W + i * NW, ti = tile_ti<NB>(idx);
+    if constexpr (HC::is_diag(idx)) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = q + 4 * g;
+        double v = 0.0;
+        if constexpr (ti < NB - 1) {
+          if (c < 8) v = t1h[ti * 128 + row * 8 + c];
+          else if (row >= 8) v = loops[ti * 64 + (row - 8) * 8 + (c - 8)];
+          else v = t1h[ti * 128 + c * 8 + row];           // (row, 8 + cc) = (8 + cc, row): c = 8 + cc
+        } else {
+          if (c < 8 && row < 8) v = loops[ti * 64 + row * 8 + c];
+        }
+        acc[i][g] = v;
+      }
+    }
+  });
+  __syncthreads();
+}
+
+template <int NB, int NW, int W, bool HF = false>
 __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int* __restrict__ kmeta_g,
                                                      const double* __restrict__ theta_g, int q, int c, int lane, double* slab,
                                                      d4 (&acc)[(NB * (NB + 1) / 2 + NW - 1) / NW]) {
@@ -472,6 +573,13 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
   constexpr int NOWN0 = SO::count(W);                   // slab blocks of this wave (may be none)
   constexpr int NOWN = NOWN0 > 0 ? NOWN0 : 1;            // (array extents)
   static_assert(MINE >= 5, "five gaps are used");
+  using HC = HalfCover<NB, NW>;
+  constexpr int NI0 = HF ? HC::irr_count(W) : 0, NI = NI0 > 0 ? NI0 : 1;      // operands of two arbitrary units (HF)
+  int ioff[NI];
+  sfor<0, NI0>([&](auto kc) {
+    constexpr int k = decltype(kc)::value, x = HC::irr_x(W, k), y = HC::irr_y(W, k);
+    ioff[k] = c < 8 ? (x >> 1) * 64 + q * 16 + (x & 1) * 8 + c : (y >> 1) * 64 + q * 16 + (y & 1) * 8 + (c - 8);
+  });
   typedef const i4 __attribute__((address_space(4)))* c_i4_p;
   const c_i4_p kmeta = (c_i4_p)(unsigned long long)kmeta_g;
   const c_f64_p theta_s = (c_f64_p)(unsigned long long)theta_g;
@@ -504,10 +612,13 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
     });
     sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; slab[o + SO::block(W, j) * 64 + lane] = own[j]; });
   };
-  auto read_slab = [&](double (&v)[NB], int o) { sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; v[b] = slab[o + b * 64 + lane]; }); };
+  auto read_slab = [&](double (&v)[NB], double (&vi)[NI], int o) {
+    sfor<0, NB>([&](auto bc) { constexpr int b = decltype(bc)::value; v[b] = slab[o + b * 64 + lane]; });
+    sfor<0, NI0>([&](auto kc) { constexpr int k = decltype(kc)::value; vi[k] = slab[o + ioff[k]]; });
+  };
   auto exchange = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-  double rawa[ROM_MAX_NT][NOWN], rawb[ROM_MAX_NT][NOWN], thB[ROM_MAX_NT], thN[ROM_MAX_NT], va[NB], vb[NB];
+  double rawa[ROM_MAX_NT][NOWN], rawb[ROM_MAX_NT][NOWN], thB[ROM_MAX_NT], thN[ROM_MAX_NT], va[NB], vb[NB], ia[NI], ib[NI];
   sfor<0, ROM_MAX_NT>([&](auto tc) { sfor<0, NOWN0>([&](auto jc) { rawa[decltype(tc)::value][decltype(jc)::value] = 0.0; rawb[decltype(tc)::value][decltype(jc)::value] = 0.0; }); });
   // prologue: slabs 0 and 1 into LDS, va <- slab 0, raw buffers <- k-steps 2 and 3, scalars up to k-step 4
   constexpr int SL = NB * 64;
@@ -524,12 +635,12 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
   thetas(thB, k2); thetas(thN, k3);
   i4 m4 = kmeta[8], k4 = kmeta[9];
   exchange();
-  read_slab(va, o0);
+  read_slab(va, ia, o0);
 
   // One iteration, specialised by the term count NTS of the slab it BUILDS (k-step ks + 2).  Term counts fall along the
   // table, so the k-step it loads (ks + 4) has at most NTS terms: NTS rows are fetched (a fixed number of loads in flight:
   // the compiler can then wait for exactly the older buffer instead of vmcnt(0)), the build two iterations later uses its own.
-  auto step = [&](auto ntc, double (&vc)[NB], double (&vn)[NB], double (&raw)[ROM_MAX_NT][NOWN], int ks) {
+  auto step = [&](auto ntc, double (&vc)[NB], double (&vn)[NB], double (&ic_)[NI], double (&in_)[NI], double (&raw)[ROM_MAX_NT][NOWN], int ks) {
     constexpr int NTS = decltype(ntc)::value;
     double thNN[ROM_MAX_NT];
     i4 m5, k5;
@@ -537,8 +648,12 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
       constexpr int i = decltype(ic)::value;
       constexpr int idx = W + i * NW;
       constexpr int ti = tile_ti<NB>(idx), tj = tile_tj<NB>(idx);
-      asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(vc[ti]), "v"(vc[tj]));
-      if constexpr (i == 0) read_slab(vn, o1);
+      if constexpr (!HF) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(vc[ti]), "v"(vc[tj]));
+      else if constexpr (HC::is_empty(idx)) {}            // (its blocks come out of other tiles: mw_half_fixup)
+      else if constexpr (HC::is_host(idx)) { constexpr int k = HC::irr_of_slot(W, i); asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %1, %0" : "+v"(acc[i]) : "v"(ic_[k])); }
+      else if constexpr (HC::is_t1(idx)) { constexpr int k = HC::irr_of_slot(W, i); asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(vc[ti]), "v"(ic_[k])); }
+      else asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(vc[ti]), "v"(vc[tj]));
+      if constexpr (i == 0) read_slab(vn, in_, o1);
       if constexpr (i == 1) {
         double own[NOWN];
         sfor<0, NOWN0>([&](auto jc) { constexpr int j = decltype(jc)::value; own[j] = thB[0] * raw[0][j]; });
@@ -573,8 +688,8 @@ __device__ __forceinline__ void proj_main_uniform_mw(const RomDev& p, const int*
     const int end = NTS == 1 ? p.nku : p.uend[NTS - 1] - 2;
 #pragma unroll 1
     for (; ks < end; ks += 2) {
-      step(std::integral_constant<int, NTS>{}, va, vb, rawa, ks);
-      step(std::integral_constant<int, NTS>{}, vb, va, rawb, ks + 1);
+      step(std::integral_constant<int, NTS>{}, va, vb, ia, ib, rawa, ks);
+      step(std::integral_constant<int, NTS>{}, vb, va, ib, ia, rawb, ks + 1);
     }
   });
 }
@@ -962,7 +1077,7 @@ __device__ __forceinline__ int fused_solve_sw(const RomDev& p, d4 (&acc)[NB * (N
   return bad;
 }
 
-template <int NB, int NW, int W, bool SK = false, bool GR = false>
+template <int NB, int NW, int W, bool SK = false, bool GR = false, bool HF = false>
 __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw, int64_t s, int lane,
                                               double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                               int* __restrict__ info, double* __restrict__ w_r = nullptr,
@@ -985,7 +1100,7 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
     // (round 1's loop -- per-lane theta indices, two slab buffers, __syncthreads() per k-step -- reached 0.50 of the MFMA peak
     // at r = 120 where this one reaches 0.7; it is gone: its run-time indexing of the phase tables inside RomDev made hipcc keep a
     // copy of the kernel arguments in scratch memory once the fused epilogue was added)
-    proj_main_uniform_mw<NB, NW, W>(p, kpat, theta_s, q, c, lane, slab, acc);
+    proj_main_uniform_mw<NB, NW, W, HF>(p, kpat, theta_s, q, c, lane, slab, acc);
   } else if ((p.clock_probe & 15) != 3) {      // (bits 4 / 5: timing experiments without table loads / without scalar loads)
     if constexpr (NW == 1 && GR) {
       if (ext_s != nullptr) proj_main_grouped<NB>(p, kpat, ext_s, q, c, acc);
@@ -1038,6 +1153,7 @@ __device__ __forceinline__ void rom_proj_body(const RomDev& p, const double* thw
 
   // let the last MFMAs retire before their results are read (no hazard padding around inline asm)
   mfma_drain(acc);
+  if constexpr (NW > 1 && HF) mw_half_fixup<NB, NW, W>(acc, slab, lane);      // from here on: the aligned block triangle
   if constexpr (NW == 1) {
     if (kparts > 1) {
       if (kpart > 0) {
@@ -1237,7 +1353,7 @@ __device__ __forceinline__ void rom_proj_entry_splitk(RomDev p, const double* __
 
 // NW waves share one sample (each owns every NW-th tile of the upper block triangle); a
 // workgroup is max(4, NW) waves = max(4, NW)/NW samples.
-template <int NB, int NW, bool GR = false>
+template <int NB, int NW, bool GR = false, bool HF = false>
 __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                        int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
@@ -1278,33 +1394,33 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
                                        NB <= 5 ? mt_sw + wave * ROM_SW_LDS : nullptr, ext_s);
   } else if constexpr (NW == 4) {
     switch (wave % 4) {
-      case 0: rom_proj_body<NB, 4, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 1: rom_proj_body<NB, 4, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 2: rom_proj_body<NB, 4, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      default: rom_proj_body<NB, 4, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 0: rom_proj_body<NB, 4, 0, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 1: rom_proj_body<NB, 4, 1, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 2: rom_proj_body<NB, 4, 2, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      default: rom_proj_body<NB, 4, 3, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
     }
   } else {
     switch (wave % 8) {
-      case 0: rom_proj_body<NB, 8, 0>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 1: rom_proj_body<NB, 8, 1>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 2: rom_proj_body<NB, 8, 2>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 3: rom_proj_body<NB, 8, 3>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 4: rom_proj_body<NB, 8, 4>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 5: rom_proj_body<NB, 8, 5>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      case 6: rom_proj_body<NB, 8, 6>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
-      default: rom_proj_body<NB, 8, 7>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 0: rom_proj_body<NB, 8, 0, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 1: rom_proj_body<NB, 8, 1, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 2: rom_proj_body<NB, 8, 2, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 3: rom_proj_body<NB, 8, 3, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 4: rom_proj_body<NB, 8, 4, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 5: rom_proj_body<NB, 8, 5, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      case 6: rom_proj_body<NB, 8, 6, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
+      default: rom_proj_body<NB, 8, 7, false, false, HF>(p, thw, s, lane, Ar, Br, factor, info, nullptr, qoi_r, slab, theta_u, kpat); break;
     }
   }
   trace_end(p.trace, blockIdx.x);
 }
 
 
-template <int NB, int NW>
+template <int NB, int NW, bool HF = false>
 __global__ __launch_bounds__((NW > 4 ? NW : 4) * 64, (NW == 4 && NB <= 8) ? 3 : 2) void rom_proj_kernel(RomDev p, const double* __restrict__ theta, int64_t S,
                                                        double* __restrict__ Ar, double* __restrict__ Br, int factor,
                                                        int* __restrict__ info, double* __restrict__ w_r, double* __restrict__ qoi_r,
                                                        const int* __restrict__ kpat) {
-  rom_proj_entry<NB, NW>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
+  rom_proj_entry<NB, NW, false, HF>(p, theta, S, Ar, Br, factor, info, w_r, qoi_r, kpat);
 }
 
 }  // namespace finrom
