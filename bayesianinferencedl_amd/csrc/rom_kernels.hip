@@ -315,7 +315,7 @@ int launch_rom_proj(const RomDev& p, const double* theta, int64_t S, double* Ar,
             hipLaunchKernelGGL((rom_proj_kernel<N, W>), dim3((unsigned)((S + spb - 1) / spb)),     \
                                dim3(64 * wpb), 0, st, p, theta, S, Ar, Br, factor, info, w_r, qoi_r, p.kmeta); } break;
   // bases whose last block is at most half full: 11 % (r = 120) / 7 % (r = 200) fewer MFMAs per k-step (HalfCover, rom_proj_device.h)
-  static const bool no_half = getenv("FINROM_PROJ_NO_HALF") != nullptr;
+  const bool no_half = getenv("FINROM_PROJ_NO_HALF") != nullptr;      // (read per call: the test of the two forms flips it)
   if (p.NB >= 7 && p.r <= 16 * p.NB - 8 && !no_half) return launch_rom_proj_half(p, theta, S, Ar, Br, factor, info, st, w_r, qoi_r);
   switch (p.NB) {
     case 1: case 2: case 3: case 4: case 5:      // own translation unit (-O2)

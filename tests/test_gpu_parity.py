@@ -175,6 +175,37 @@ def test_scalar_call_surface(problems, spaces):
     assert rel(solver.forward_five_param(k5)[0].vector()[:], fo.forward_five_param(k5)) < TOL
 
 
+@pytest.mark.parametrize("m,r", [(4, 100), (12, 120), (4, 137), (4, 150), (12, 200)])
+def test_half_block_cover_gives_the_aligned_kernels_bits(problems, spaces, m, r, monkeypatch):
+    """Bases whose last 16-column block is at most half full (r mod 16 in 1..8) run the multi-wave projection kernels with the
+    last tile column and the diagonal tiles re-paired (rom_proj_device.h::HalfCover: fewer MFMAs per k-step) and move the pieces
+    into the aligned block triangle afterwards.  Every entry of A_r is still the same sum of the same products in the same
+    order: the stored A_r, the separate solve and the in-register factorisation + QoI must agree BIT FOR BIT with the aligned
+    kernels (FINROM_PROJ_NO_HALF=1, read per call).  r = 100, 137, 150: NB = 7, 9, 10 (four and eight waves per sample);
+    the oracle pins the values (psi^T psi, rom/averaged_affine_ROM.py:291-297)."""
+    from bayesianinferencedl_amd.rom.averaged_affine_ROM import AffineROMFin
+    prob = problems(m); V = spaces(m)
+    phi = oracle_basis(prob, r)
+    ro = O.AffineROMOracle(prob, phi)
+    rom = AffineROMFin(V, None, phi)
+    rng = np.random.default_rng(29)
+    S = 37
+    TH = np.exp(rng.uniform(np.log(0.1), np.log(10.0), (S, 9)))
+    full = rom._rom.solve(TH, want_state=True)
+    qonly = rom._rom.solve(TH, want_w=False)
+    monkeypatch.setenv("FINROM_PROJ_NO_HALF", "1")
+    full_a = rom._rom.solve(TH, want_state=True)
+    qonly_a = rom._rom.solve(TH, want_w=False)
+    monkeypatch.delenv("FINROM_PROJ_NO_HALF")
+    for key in ("A_r", "B_r", "w_r", "qoi_r", "info"):    # (a POD basis this wide has noise-level columns: flags may be set -- in both forms)
+        assert np.array_equal(full[key], full_a[key], equal_nan=key != "info"), key
+    assert np.array_equal(qonly["qoi_r"], qonly_a["qoi_r"], equal_nan=True) and np.array_equal(qonly["info"], qonly_a["info"])
+    for i in (0, S - 1):
+        w_r, A_r, B_r, psi = ro.forward_nine_param_reduced(TH[i], return_parts=True)
+        assert np.max(np.abs(full["A_r"][i] - A_r)) < 1e-12 * np.abs(A_r).max()
+        assert np.array_equal(full["A_r"][i], full["A_r"][i].T)
+
+
 @pytest.mark.parametrize("m,r", [(12, 80), (12, 33), (4, 16)])
 def test_grouped_projection_against_the_ungrouped_loop_and_the_oracle(problems, spaces, m, r, monkeypatch):
     """The one-wave projection kernel (r <= 80) accumulates psi^T psi grouped by sub-domain, each group divided by its
