@@ -1701,9 +1701,25 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     if ((rc = rom->ensure_fom_side(fom_cus))) return rc;
     if (rom->fom_side) fst = rom->fom_side;
   }
+  // With the sweep on its masked stream and its pre-pass off it (below), the ROM half can stay on the CALLER's stream: sub-fin
+  // averages, per-sample scalars, projection and the difference kernel then follow each other in stream order, and the library's
+  // unmasked side stream carries the pre-pass instead -- no cross-stream wait on the step's critical path (each costs 40-80 us:
+  // between two steps of the headline the GPU waited 0.33 ms).  FINROM_ROM_ON_SIDE=1: the ROM half on the side stream, as for
+  // every other caller's stream.
+  static const bool env_rom_on_side = getenv("FINROM_ROM_ON_SIDE") != nullptr;
+  static const bool env_pre_masked = getenv("FINROM_FOM_PREPASS_MASKED") != nullptr;
+  const bool pre_unmasked = fst != st && split && !env_pre_masked;
+  // Only when the caller's stream is a non-blocking one: hipExtStreamCreateWithCUMask has no flags argument, the masked stream is a
+  // BLOCKING stream, and the null stream (torch's default) serialises with it -- measured: the sweep then starts when the
+  // projection ends (29.0 instead of 20.2 ms per step).
+  unsigned st_flags = 0;
+  const bool st_nonblocking = st != nullptr && hipStreamGetFlags(st, &st_flags) == hipSuccess && (st_flags & hipStreamNonBlocking);
+  const bool rom_on_caller = pre_unmasked && !env_rom_on_side && st_nonblocking;
+  const hipStream_t rst = rom_on_caller ? st : side;      // the ROM half
+  const hipStream_t pst = rom_on_caller ? side : st;      // the FOM half's unmasked pre-pass
   auto join = [&]() {
-    if (overlap && hipEventRecord(rom->ev_join, side) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join, 0);
-    if (fst != st && hipEventRecord(rom->ev_join_fom, fst) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join_fom, 0);
+    if (overlap && !rom_on_caller && hipEventRecord(rom->ev_join, side) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join, 0);
+    if (fst != st && hipEventRecord(rom->ev_join_fom, fst) == hipSuccess) (void)hipStreamWaitEvent(st, rom->ev_join_fom, 0);      // (the sweep waited for the pre-pass)
   };
   auto fail = [&](int code) { if (overlap) (void)hipStreamSynchronize(side); if (fst != st) (void)hipStreamSynchronize(fst); return code; };
   if (split && (rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 4))) return rc;          // (reserves the FOM workspace)
@@ -1715,12 +1731,13 @@ int finrom_solve_pairs(finrom_fom_t fom, finrom_rom_t rom, const double* Sop, co
     FR_HIP(hipStreamWaitEvent(side, rom->ev_fork, 0));
     if (fst != st) FR_HIP(hipStreamWaitEvent(fst, rom->ev_fork, 0));
   }
-  if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, side))) return fail(rc);
-  // (experiment, FINROM_FOM_PREPASS_UNMASKED=1: pack + assembly on the caller's unmasked stream, only the sweep on the masked one)
-  static const bool env_pre_unmasked = getenv("FINROM_FOM_PREPASS_UNMASKED") != nullptr;
-  if (fst != st && split && env_pre_unmasked) {
-    if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, st, 1))) return fail(rc);
-    if (hipEventRecord(rom->ev_join_fom, st) != hipSuccess || hipStreamWaitEvent(fst, rom->ev_join_fom, 0) != hipSuccess) return fail(FINROM_ERR_HIP);
+  if ((rc = finrom_rom_solve(rom, theta, S, w_r, qoi_r, nullptr, nullptr, info, rst))) return fail(rc);
+  // With a masked FOM stream only the SWEEP runs on it: pack + assembly go to an unmasked stream (they take 0.1 ms there against
+  // 2.0 ms on 96 CUs beside the projection's start, and since the grouped projection loop the FOM half is the one that ends
+  // last: step 20.46 -> 20.26 ms).  FINROM_FOM_PREPASS_MASKED=1: the whole FOM half on the masked stream, as before.
+  if (pre_unmasked) {
+    if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, pst, 1))) return fail(rc);
+    if (hipEventRecord(rom->ev_join_fom, pst) != hipSuccess || hipStreamWaitEvent(fst, rom->ev_join_fom, 0) != hipSuccess) return fail(FINROM_ERR_HIP);
     if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, fst, 2))) return fail(rc);
   } else if ((rc = fom_solve_stages(fom, x, S, qoi, w, info, fst, 3))) return fail(rc);
   join();

@@ -36,9 +36,11 @@ class FinPairSolver:
         rom = self.solver_r._rom
         b = _Batch(X, self.xdim)
         S = b.S
-        qoi, qp = b.new((S, self.n_obs)); qoi_r, qrp = b.new((S, self.n_obs)); err, ep = b.new((S, self.n_obs))
-        w_r, wrp = b.new((S, rom.r)) if want_w_r else (None, None); theta, tp = b.new((S, rom.P)); info, ip = b.new((S,), "i4")
-        w, wp = (b.new((S, fom.n)) if want_w else (None, None))
+        # (every output but the flags is written in full by the call -- failed samples as NaN: no fill kernels in front of it;
+        # between two steps of the headline they were 65 us of the 0.33 ms the GPU waited)
+        qoi, qp = b.new((S, self.n_obs), zero=False); qoi_r, qrp = b.new((S, self.n_obs), zero=False); err, ep = b.new((S, self.n_obs), zero=False)
+        w_r, wrp = b.new((S, rom.r), zero=False) if want_w_r else (None, None); theta, tp = b.new((S, rom.P), zero=False); info, ip = b.new((S,), "i4")
+        w, wp = (b.new((S, fom.n), zero=False) if want_w else (None, None))
         check(lib().finrom_solve_pairs(fom._h, rom._h, self._avg._S.ptr, b.ptr, S, qp, qrp, ep, wp, wrp, tp, ip, b.stream),
               "finrom_solve_pairs")
         self._avg._S.used_on(b.stream)

@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--projection", default="direct", choices=["direct", "offline_online"],
                     help="how the timed region forms A_r: 'direct' = per-sample psi^T psi on MFMA (what the reference executes, the "
                          "headline); 'offline_online' = precomputed Gram blocks (same results, ~50x fewer ROM flops)")
+    ap.add_argument("--stream", choices=("default", "own"), default="own",
+                    help="pairs workload: the steps on a torch stream of their own (non-blocking; the ROM half of finrom_solve_pairs "
+                         "then stays on it, no cross-stream wait per step) or on torch's default (null) stream")
     ap.add_argument("--no-other", action="store_true", help="skip the extra (untimed) pass with the other --projection")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-host-io", action="store_true", help="skip the extra (untimed) host-buffer pass")
@@ -254,6 +257,13 @@ def main():
         X = torch.from_numpy(global_uniform(3, rank * S, (rank + 1) * S, pairs.xdim)).to(dev)
     from bayesianinferencedl_amd.distributed import gather_rows
 
+    if args.stream == "own":
+        # the steps run on a stream of their own (a torch stream is a non-blocking HIP stream): beside the null stream the
+        # library's CU-masked FOM stream -- a blocking stream, hipExtStreamCreateWithCUMask takes no flags -- cannot let the ROM
+        # half stay on the caller's stream (finrom_solve_pairs)
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
+
     def step():
         res = pairs.solve_pairs(X)
         if use_pg:      # the one exchange step: QoI pairs of every shard (RCCL all_gather over xGMI)
@@ -383,7 +393,7 @@ def main():
                                    f"nnz(L)={plan.nnzL}), POD basis r={args.r}, {S} samples per GPU, "
                                    "FOM sparse Cholesky + LSPG ROM + QoIs + error per sample",
                        "samples_per_gpu": S, "n_dof": ops.n, "r": args.r, "params": args.params,
-                       "projection": args.projection,
+                       "projection": args.projection, "stream": args.stream,
                        "flops_per_pair": int(sum(fl.values())), "failed_samples": n_bad},
             "roofline": roof,
             "cpu_baseline": cpu,
