@@ -12,14 +12,17 @@ def shard_bounds(total: int, rank: int, world: int):
     return lo, min(total, lo + per)
 
 
-def gather_rows(local, world: int, total: int | None = None, force: bool = False):
+def gather_rows(local, world: int, total: int | None = None, force: bool = False, async_op: bool = False):
     """All ranks contribute ``local`` [rows_r, d] (torch tensor; every rank but the last must hold
     ceil(total/world) rows); returns the concatenation [total, d] on every rank.  ``force``: run the
-    collective even in a one-rank group (the RCCL rehearsal of bench.py --force-pg)."""
+    collective even in a one-rank group (the RCCL rehearsal of bench.py --force-pg).
+    ``async_op``: returns (result, work) -- the collective runs on the backend's own stream behind what is queued on the
+    current one, and the caller's later kernels do not wait for it; ``work.wait()`` (None where no collective ran) makes the
+    current stream wait.  The caller keeps ``local`` and the result alive until then."""
     import torch
     import torch.distributed as dist
     if world == 1 and not force:
-        return local
+        return (local, None) if async_op else local
     per = local.shape[0]
     if total is not None:
         per = -(-total // world)
@@ -27,6 +30,10 @@ def gather_rows(local, world: int, total: int | None = None, force: bool = False
             pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             local = torch.cat([local, pad], 0)
     out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if async_op:
+        local = local.contiguous()
+        work = dist.all_gather_into_tensor(out, local, async_op=True)
+        return (out if total is None else out[:total]), work
     dist.all_gather_into_tensor(out, local.contiguous())
     return out if total is None else out[:total]
 

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 run: nccl (= RCCL over xGMI, one rank per GPU) or gloo (host "
                          "gather; ranks may then share a GPU: rehearsal of the N > 1 path on a one-GPU box)")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="(RCCL) every step waits for its own all-gather before the next step's kernels start (default: the gather "
+                         "of step i runs beside the kernels of step i + 1; all joined before the clock stops)")
     ap.add_argument("--force-pg", action="store_true",
                     help="create the torch.distributed process group and run the per-step gather even with ONE rank (the "
                          "collective then really executes: RCCL communicator init + all_gather_into_tensor on device tensors at "
@@ -264,14 +267,25 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.Stream(dev))
 
+    pending = []      # (RCCL) the steps' all-gathers in flight: each runs on the communicator's stream behind its own step's kernels
+                      # and beside the NEXT step's -- the path has no dependence on the gathered rows; joined at the fence
+
     def step():
         res = pairs.solve_pairs(X)
         if use_pg:      # the one exchange step: QoI pairs of every shard (RCCL all_gather over xGMI)
             loc = torch.cat([res["qoi"], res["qoi_r"]], dim=1)
-            res["gathered"] = gather_rows(loc if args.backend == "nccl" else loc.cpu(), world, force=True)
+            if args.backend == "nccl" and not args.sync_gather:
+                res["gathered"], work = gather_rows(loc, world, force=True, async_op=True)
+                pending.append((work, loc, res["gathered"]))
+            else:
+                res["gathered"] = gather_rows(loc if args.backend == "nccl" else loc.cpu(), world, force=True)
         return res
 
     def fence():
+        for work, _, _ in pending:                       # the current stream waits for every gather of the region
+            if work is not None:
+                work.wait()
+        pending.clear()
         if use_pg:
             dist.barrier()
         torch.cuda.synchronize()

@@ -426,13 +426,16 @@ int finrom_sampler_draw_seeded(finrom_sampler_t h, uint64_t seed, int64_t first_
                                double* xi_out, void* stream);
 
 /* ---- the dataset-loop body for S samples in one call ---------------------------------- *
- * (deep_learning/generate_fin_dataset.py:93-100):  FOM solve + QoI on the caller's stream
- * (large batches of the r <= 80 / m <= 12 pairing: on a library stream restricted to three CUs
- * of every shader engine -- the HBM-bound sweep then shares fewer SIMDs with the projection,
- * DESIGN.md 5; FINROM_FOM_CUS=0 keeps the caller's stream);
+ * (deep_learning/generate_fin_dataset.py:93-100):  FOM solve + QoI on the caller's stream;
  * concurrently, on a stream owned by the library, theta = Sop x (sub-fin averages of the
  * field, or of the interpolated per-fin conductivities) and the LSPG reduced solve + QoI;
- * then err = qoi - qoi_r.  The two halves are independent and are joined with HIP events
+ * then err = qoi - qoi_r.  (Large batches of the r <= 80 / m <= 12 pairing: the FOM's band
+ * sweep runs on a library stream restricted to three CUs of every shader engine -- the
+ * HBM-bound sweep then shares fewer SIMDs with the projection, DESIGN.md 5 -- its pack +
+ * assembly pre-pass on an unmasked stream, and when the caller's stream is a non-blocking
+ * one the ROM half stays on it: no cross-stream wait on the call's critical path.
+ * FINROM_FOM_CUS=0 keeps the FOM half on the caller's stream.)
+ * The two halves are independent and are joined with HIP events
  * on the caller's stream (every output is ready in stream order behind the call),
  * so the HBM-bound sparse solve overlaps the MFMA-bound projection.
  * Sop: device [P x xdim] (P = the ROM's parameter count, xdim = the FOM's).  Optional

@@ -64,12 +64,16 @@ def test_cu_masked_fom_stream_gives_the_same_outputs():
     """Beside the one-wave projection kernel the FOM sweep of a large batch runs on a library stream masked to three CUs per
     shader engine (finrom_solve_pairs).  Where the kernels run must not change what they compute: the gathered QoI pairs
     of the masked default, of an unmasked run (FINROM_FOM_CUS=0) and of another mask (64 CUs) have the same checksum."""
-    def run(env):
+    def run(env, *extra):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--samples", "20000", "--steps", "2", "--warmup", "1",
-                            "--cpu-samples", "0", "--no-other", "--no-host-io", "--no-profile"], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, **env))
+                            "--cpu-samples", "0", "--no-other", "--no-host-io", "--no-profile", *extra], capture_output=True, text=True,
+                           timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stdout + r.stderr
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     masked, plain, other = run({}), run({"FINROM_FOM_CUS": "0"}), run({"FINROM_FOM_CUS": "64"})
-    assert masked["config"]["failed_samples"] == 0
+    assert masked["config"]["failed_samples"] == 0 and masked["config"]["stream"] == "own"
     assert masked["gathered_sha256"] == plain["gathered_sha256"] == other["gathered_sha256"]
+    # ... nor which stream carries which half: the steps on torch's null stream (the masked stream is a blocking one: the ROM half
+    # then runs on the library's side stream), the ROM half forced to the side stream, the whole FOM half on the masked stream
+    for env, extra in (({}, ("--stream", "default")), ({"FINROM_ROM_ON_SIDE": "1"}, ()), ({"FINROM_FOM_PREPASS_MASKED": "1"}, ())):
+        assert run(env, *extra)["gathered_sha256"] == masked["gathered_sha256"], (env, extra)

@@ -74,6 +74,9 @@ def test_one_rank_rccl_process_group_and_device_gather():
     # and without the launcher: bench.py --force-pg makes its own one-rank rendezvous
     alone = _bench(argv)
     assert alone["process_group"]["backend"] == "nccl" and alone["gathered_sha256"] == plain["gathered_sha256"]
+    # the default lets the gather of step i run beside the kernels of step i + 1 (joined before the clock stops); --sync-gather
+    # makes every step wait for its own: the same rows either way
+    assert _bench(argv + ["--sync-gather"])["gathered_sha256"] == plain["gathered_sha256"]
 
 
 def test_c_abi_gather_one_rank():

@@ -51,5 +51,6 @@ python bench.py --steps 2 --warmup 1 --cpu-samples 0 --no-host-io --no-other --p
 FINROM_NO_OVERLAP=1 python bench.py --steps 2 --warmup 1 --cpu-samples 0 --no-host-io --no-other --params field --m 20 --r 200 --samples 125000 > $out/bench_c4_full_in_turn.log 2>&1 || exit 1
 echo "[7] the driver's own command"
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_final.log 2>&1 || exit 1
+python bench.py --gpus 1 --steps 20 --warmup 5 --stream default --cpu-samples 0 --no-other > $out/bench_final_default_stream.log 2>&1 || exit 1
 python tools/pmc_summary.py $out > $out/summary.log 2>&1
 cat $out/summary.log

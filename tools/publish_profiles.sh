@@ -6,7 +6,7 @@ src=gpurun_out/prof_${1:?tag}; pre=profiles/${2:?prefix}
 for k in overlapped serial c3 c4 oo_overlapped hmc; do
   [ -f $src/$k/run_kernel_stats.csv ] && cp $src/$k/run_kernel_stats.csv ${pre}_${k}_kernel_stats.csv
 done
-for k in overlapped serial c3 c4 oo_overlapped hmc c4_full c4_full_in_turn final; do
+for k in overlapped serial c3 c4 oo_overlapped hmc c4_full c4_full_in_turn final final_default_stream; do
   [ -f $src/bench_$k.log ] && grep -h '^{' $src/bench_$k.log | tail -1 > ${pre}_${k}_bench.json
 done
 for k in headline c3 c4 c4full; do [ -f $src/pmc_summary_$k.json ] && cp $src/pmc_summary_$k.json ${pre}_pmc_summary_$k.json; done
