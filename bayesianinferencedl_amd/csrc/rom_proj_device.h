@@ -1380,10 +1380,10 @@ __device__ __forceinline__ void rom_proj_entry(RomDev p, const double* __restric
   if constexpr (NW == 1) {
     const double* ext_s = nullptr;
     if constexpr (GR) {
-      // (the grouped form divides by the conductivities: a sample with a zero, subnormal, huge or non-finite one takes the
-      // ungrouped loop -- same sums as a handle without the grouped tables)
+      // (the grouped form divides by the conductivities: a sample with a zero, tiny (< 1e-60), huge (> 1e60) or non-finite one
+      // takes the ungrouped loop -- same sums as a handle without the grouped tables)
       const double tl = lane < p.P ? theta[s * p.P + lane] : 1.0;
-      const bool plain = __ballot(!(__builtin_fabs(tl) > 1e-100 && __builtin_fabs(tl) < 1e100)) == 0;
+      const bool plain = __ballot(!(__builtin_fabs(tl) > 1e-60 && __builtin_fabs(tl) < 1e60)) == 0;      // (ratios are squared: <= 1e240)
       if (p.ext != nullptr && plain) {
         const unsigned long long ea = (unsigned long long)(p.ext + ((int64_t)blockIdx.x * WPB + wave) * p.n_ext);
         ext_s = (const double*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ea >> 32)) << 32) |

@@ -225,15 +225,18 @@ def test_grouped_projection_against_the_ungrouped_loop_and_the_oracle(problems, 
     rng = np.random.default_rng(23)
     S = 301                                                # (> 64: the batch kernel; a ragged last workgroup)
     TH = np.exp(rng.uniform(np.log(0.1), np.log(10.0), (S, 9)))      # (the dataset's range, generate_fin_dataset.py:75)
-    odd = {5: 0.0, 17: 1e-300, 40: 1e200, 77: np.nan, 130: -0.0, 300: np.inf}
+    odd = {5: 0.0, 17: 1e-300, 40: 1e200, 77: np.nan, 130: -0.0, 300: np.inf, 222: 1e61, 223: 1e-61}
     for i, v in odd.items():
         TH[i, i % 9] = v
     TH[200, 3] = -2.5                                      # a negative conductivity divides like any other: grouped
+    TH[201, 0], TH[201, 8] = 1e50, 1e-50                   # ... and so do 100 decades between two sub-domains (ratio squared: 1e200)
     g = rom_g._rom.solve(TH, want_state=True)
     u = rom_u._rom.solve(TH, want_state=True)
     assert np.array_equal(g["info"], u["info"])
     plain = np.array([i not in odd for i in range(S)])
-    assert (g["info"][plain & (np.arange(S) != 200)] == 0).all()
+    assert (g["info"][plain & (np.arange(S) != 200) & (np.arange(S) != 201)] == 0).all()
+    sc201 = np.abs(u["A_r"][201]).max()
+    assert np.isfinite(sc201) and np.max(np.abs(g["A_r"][201] - u["A_r"][201])) < 1e-12 * sc201
     for key in ("A_r", "B_r", "w_r", "qoi_r"):
         for i in odd:                                      # the ungrouped loop, in the same launch
             assert np.array_equal(g[key][i], u[key][i], equal_nan=True), (key, i)
