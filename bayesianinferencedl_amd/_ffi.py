@@ -120,6 +120,7 @@ SIGNATURES = {
     "finrom_fom_set_small_max": (C.c_int, [C.c_void_p, C.c_int32]),
     "finrom_fom_gradient": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64] + [C.c_void_p] * 5),
     "finrom_rom_create": (C.c_int, [C.POINTER(RomDesc), C.POINTER(C.c_void_p)]),
+    "finrom_rom_grouped_tables": (C.c_int, [C.POINTER(RomDesc), c_i32p, c_i32p, c_i32p, C.POINTER(C.c_int64), c_i32p, c_f64p, c_i32p]),
     "finrom_rom_destroy": (None, [C.c_void_p]),
     "finrom_rom_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -148,7 +149,7 @@ SIGNATURES = {
     "finrom_comm_destroy": (C.c_int, [C.c_void_p]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 # finrom_fom_last_path codes (include/finrom.h)
 FOM_PATHS = {0: "none", 1: "small_lds", 2: "small_global", 3: "interpreter", 4: "band_registers", 5: "band_lds_4wave",
              6: "band_lds_1wave", 7: "band_registers_qoi", 8: "band_lds_4wave_qoi"}

@@ -1084,10 +1084,10 @@ int finrom_fom_gradient(finrom_fom_t h, const double* x, const double* data, int
 // ---------------------------------------------------------------------------------------
 // ROM
 // ---------------------------------------------------------------------------------------
-int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
-  if (!a || !out) { set_error("rom_create: null argument"); return FINROM_ERR_ARG; }
-  *out = nullptr;
+namespace {
+int validate_rom_desc(const finrom_rom_desc* a) {
   if (a->n <= 0 || a->r <= 0 || a->P < 0 || a->P > 31 || a->n_obs < 0 || a->nterms < 0) { set_error("rom_create: inconsistent sizes"); return FINROM_ERR_ARG; }
+  if (!a->row_ptr || (a->nterms > 0 && (!a->term_p || !a->term_val))) { set_error("rom_create: null table"); return FINROM_ERR_ARG; }
   if (a->row_ptr[0] != 0 || a->row_ptr[a->n] != a->nterms) { set_error("rom_create: invalid row_ptr"); return FINROM_ERR_ARG; }
   for (int i = 0; i < a->n; ++i) if (a->row_ptr[i + 1] < a->row_ptr[i]) { set_error("rom_create: invalid row_ptr"); return FINROM_ERR_ARG; }
   for (int t = 0; t < a->nterms; ++t) if (a->term_p[t] < 0 || a->term_p[t] > a->P) { set_error("rom_create: invalid term_p"); return FINROM_ERR_ARG; }
@@ -1100,15 +1100,147 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
       seen |= 1u << a->term_p[t];
     }
   }
+  return 0;
+}
+
+// rows with a term, sorted by term count (descending)
+std::vector<int> rows_by_term_count(const finrom_rom_desc* a) {
+  auto cnt = [&](int row) { return a->row_ptr[row + 1] - a->row_ptr[row]; };
+  std::vector<int> order;
+  for (int i = 0; i < a->n; ++i) if (cnt(i) > 0) order.push_back(i);
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cnt(x) > cnt(y); });
+  return order;
+}
+
+// pattern-uniform k-steps (RomDev::tvu): four rows that share ONE list of theta indices; sorted by term count, descending
+struct KStep { std::vector<int> pat; int rows[4]; };
+std::vector<KStep> uniform_ksteps(const finrom_rom_desc* a, const std::vector<int>& order) {
+  std::vector<KStep> ksteps;
+  auto pattern = [&](int row) { return std::vector<int>(a->term_p + a->row_ptr[row], a->term_p + a->row_ptr[row + 1]); };
+  std::vector<int> byp(order);
+  std::stable_sort(byp.begin(), byp.end(), [&](int x, int y) { return pattern(x) < pattern(y); });
+  std::vector<int> left;
+  for (size_t i0 = 0; i0 < byp.size();) {
+    size_t i1 = i0;
+    while (i1 < byp.size() && pattern(byp[i1]) == pattern(byp[i0])) ++i1;
+    size_t i = i0;
+    for (; i + 4 <= i1; i += 4) ksteps.push_back({pattern(byp[i]), {byp[i], byp[i + 1], byp[i + 2], byp[i + 3]}});
+    for (; i < i1; ++i) left.push_back(byp[i]);
+    i0 = i1;
+  }
+  // leftovers: consecutive rows share a k-step as long as the union of their patterns has at most ROM_MAX_NT entries
+  KStep cur{{}, {-1, -1, -1, -1}};
+  int fill = 0;
+  auto flush = [&]() { if (fill) ksteps.push_back(cur); cur = KStep{{}, {-1, -1, -1, -1}}; fill = 0; };
+  for (int row : left) {
+    std::vector<int> u = cur.pat;
+    for (int pp : pattern(row)) if (std::find(u.begin(), u.end(), pp) == u.end()) u.push_back(pp);
+    if (fill == 4 || (int)u.size() > 4) { flush(); u = pattern(row); }
+    cur.pat = u; cur.rows[fill++] = row;
+  }
+  flush();
+  std::stable_sort(ksteps.begin(), ksteps.end(), [](const KStep& x, const KStep& y) { return x.pat.size() > y.pat.size(); });
+  return ksteps;
+}
+
+// ---- the same k-steps GROUPED by their leading parameter (proj_main_grouped, NB <= 5) ----------------------------------
+// A k-step whose rows carry {theta_d} or {1, theta_d} belongs to group d and is accumulated DIVIDED by theta_d: its slab is
+// T_d (no arithmetic at all) or T_d + (1/theta_d) T_0 (one multiply-add per block); the accumulators are rescaled where the
+// group changes -- by (theta_d / theta_e)^2 between groups d and e, by theta_d^2 after the last -- so that the sum is the
+// one the ungrouped loop forms, up to rounding.  Everything else (rows that touch two parameters, merged leftovers) comes
+// first, at scale 1, with the usual coefficients.  The per-sample scalars (1, theta, 1 / theta, the rescale factors) are
+// one row of RomDev::ext, filled by rom_ext_kernel ahead of the projection kernel; the records name them by index.
+struct GroupedTables { std::vector<double> tvg; std::vector<int> kmg, def; int nkg = 0, n_ext = 0, ext_final = 0; };
+bool build_grouped_tables(const finrom_rom_desc* a, const std::vector<KStep>& ksteps, int rp, GroupedTables& out) {
+  const int r = a->r;
+  struct GStep { int group; std::vector<int> pat; const int* rows; };
+  std::vector<GStep> gs;
+  for (const KStep& ks : ksteps) {
+    if (ks.rows[0] < 0 && ks.rows[1] < 0 && ks.rows[2] < 0 && ks.rows[3] < 0) continue;      // (padding k-steps of the ungrouped list)
+    int group = 0;
+    std::vector<int> pat = ks.pat;
+    if (pat.size() == 1 && pat[0] != 0) group = pat[0];
+    else if (pat.size() == 2 && (pat[0] == 0) != (pat[1] == 0)) { group = pat[0] ? pat[0] : pat[1]; pat = {group, 0}; }
+    gs.push_back({group, pat, ks.rows});
+  }
+  std::stable_sort(gs.begin(), gs.end(), [](const GStep& x, const GStep& y) { return x.group < y.group; });
+  std::vector<int> groups;
+  for (const GStep& g : gs) if (g.group && (groups.empty() || groups.back() != g.group)) groups.push_back(g.group);
+  const int P = a->P, n_ext = 1 + 2 * P + (int)groups.size() + 1;
+  if (groups.empty() || n_ext > 64) return false;
+  // ext[0] = 1, ext[p] = theta_p, ext[P + p] = 1 / theta_p, then one factor per change of group; as (numerator, denominator, squared)
+  std::vector<int> def(3 * (size_t)n_ext, 0);
+  for (int pp = 1; pp <= P; ++pp) { def[3 * pp] = pp; def[3 * (P + pp) + 1] = pp; }
+  std::vector<int> factor_of(groups.size() + 1);
+  for (size_t g = 0; g <= groups.size(); ++g) {
+    const int e = 1 + 2 * P + (int)g;
+    def[3 * e] = g == 0 ? 0 : groups[g - 1]; def[3 * e + 1] = g == groups.size() ? 0 : groups[g]; def[3 * e + 2] = 1;
+    factor_of[g] = e;
+  }
+  std::vector<double>& tvg = out.tvg; std::vector<int>& kmg = out.kmg;
+  tvg.clear(); kmg.clear();
+  int slot = 0, prev = 0;
+  bool first = true;
+  for (const GStep& g : gs) {
+    const int nt = (int)g.pat.size();
+    int rec[8] = {slot, nt, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < nt; ++t) rec[4 + t] = g.group ? (t == 0 ? 0 : P + g.group) : g.pat[t];
+    if (rec[4] == 0) rec[2] |= 1;                       // the first coefficient is 1: its rows are the slab as they are
+    if (g.group != prev && !first) {                   // (nothing to rescale in front of the very first k-step)
+      const size_t gi = std::find(groups.begin(), groups.end(), g.group) - groups.begin();
+      rec[2] |= 2; rec[3] = factor_of[gi];             // (from scale 1: (1 / theta_d)^2)
+    }
+    prev = g.group; first = false;
+    kmg.insert(kmg.end(), rec, rec + 8);
+    for (int t = 0; t < nt; ++t)
+      for (int q = 0; q < 4; ++q) {
+        const size_t base = tvg.size();
+        tvg.resize(base + rp, 0.0);
+        const int row = g.rows[q];
+        if (row < 0) continue;
+        for (int tt = a->row_ptr[row]; tt < a->row_ptr[row + 1]; ++tt)
+          if (a->term_p[tt] == g.pat[t]) for (int col = 0; col < r; ++col) tvg[base + col] += a->term_val[(size_t)tt * r + col];
+      }
+    slot += nt;
+  }
+  // zero k-steps fill the list up to a multiple of three (the loop rotates three slab buffers) and serve the pipeline's reads
+  // of the records / rows of the k-steps behind the last one
+  int nkg = (int)gs.size();
+  const int zslot = slot;
+  tvg.resize(tvg.size() + (size_t)4 * 4 * rp, 0.0);
+  while (nkg % 3) { int rec[8] = {zslot, 1, 1, 0, 0, 0, 0, 0}; kmg.insert(kmg.end(), rec, rec + 8); ++nkg; }
+  for (int k = 0; k < 8; ++k) { int rec[8] = {zslot, 1, 1, 0, 0, 0, 0, 0}; kmg.insert(kmg.end(), rec, rec + 8); }
+  out.def = def; out.nkg = nkg; out.n_ext = n_ext; out.ext_final = factor_of[groups.size()];
+  return true;
+}
+}  // namespace
+
+// Host only (no device needed): the grouped tables finrom_rom_create builds for r <= 80, for tests of the host logic.
+int finrom_rom_grouped_tables(const finrom_rom_desc* a, int32_t* nkg, int32_t* n_ext, int32_t* ext_final, int64_t* n_slots,
+                              int32_t* kmg, double* tvg, int32_t* ext_def) {
+  if (!a || !nkg || !n_ext || !ext_final || !n_slots) { set_error("rom_grouped_tables: null argument"); return FINROM_ERR_ARG; }
+  if (int rc = validate_rom_desc(a)) return rc;
+  const int NB = (a->r + 15) / 16, rp = 16 * NB;
+  GroupedTables g;
+  if (NB > 5 || !build_grouped_tables(a, uniform_ksteps(a, rows_by_term_count(a)), rp, g)) { *nkg = 0; *n_ext = 0; *ext_final = 0; *n_slots = 0; return 0; }
+  *nkg = g.nkg; *n_ext = g.n_ext; *ext_final = g.ext_final; *n_slots = (int64_t)(g.tvg.size() / ((size_t)4 * rp));
+  if (kmg) std::memcpy(kmg, g.kmg.data(), g.kmg.size() * sizeof(int));
+  if (tvg) std::memcpy(tvg, g.tvg.data(), g.tvg.size() * sizeof(double));
+  if (ext_def) std::memcpy(ext_def, g.def.data(), g.def.size() * sizeof(int));
+  return 0;
+}
+
+int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
+  if (!a || !out) { set_error("rom_create: null argument"); return FINROM_ERR_ARG; }
+  *out = nullptr;
+  if (int rc = validate_rom_desc(a)) return rc;
   const int r = a->r, NB = (r + 15) / 16, rp = 16 * NB;
   if (NB > 13) { set_error("rom_create: basis size > 208 not supported"); return FINROM_ERR_UNSUPPORTED; }
 
   // rows sorted by term count (descending) so that the 4 rows of a k-step need the same number
   // of slots and the k-steps fall into a few phases of constant term count NT
   auto cnt = [&](int row) { return a->row_ptr[row + 1] - a->row_ptr[row]; };
-  std::vector<int> order;
-  for (int i = 0; i < a->n; ++i) if (cnt(i) > 0) order.push_back(i);
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return cnt(x) > cnt(y); });
+  const std::vector<int> order = rows_by_term_count(a);
   const int nrows = (int)order.size();
   const int nk = (nrows + 3) / 4;
   auto* h = new finrom_rom_s();
@@ -1153,32 +1285,7 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
   std::vector<double> tvu; std::vector<int> kpat, kmeta;
   d.n_uphases = 0;
   {
-    struct KStep { std::vector<int> pat; int rows[4]; };
-    std::vector<KStep> ksteps;
-    auto pattern = [&](int row) { return std::vector<int>(a->term_p + a->row_ptr[row], a->term_p + a->row_ptr[row + 1]); };
-    std::vector<int> byp(order);
-    std::stable_sort(byp.begin(), byp.end(), [&](int x, int y) { return pattern(x) < pattern(y); });
-    std::vector<int> left;
-    for (size_t i0 = 0; i0 < byp.size();) {
-      size_t i1 = i0;
-      while (i1 < byp.size() && pattern(byp[i1]) == pattern(byp[i0])) ++i1;
-      size_t i = i0;
-      for (; i + 4 <= i1; i += 4) ksteps.push_back({pattern(byp[i]), {byp[i], byp[i + 1], byp[i + 2], byp[i + 3]}});
-      for (; i < i1; ++i) left.push_back(byp[i]);
-      i0 = i1;
-    }
-    // leftovers: consecutive rows share a k-step as long as the union of their patterns has at most ROM_MAX_NT entries
-    KStep cur{{}, {-1, -1, -1, -1}};
-    int fill = 0;
-    auto flush = [&]() { if (fill) ksteps.push_back(cur); cur = KStep{{}, {-1, -1, -1, -1}}; fill = 0; };
-    for (int row : left) {
-      std::vector<int> u = cur.pat;
-      for (int pp : pattern(row)) if (std::find(u.begin(), u.end(), pp) == u.end()) u.push_back(pp);
-      if (fill == 4 || (int)u.size() > 4) { flush(); u = pattern(row); }
-      cur.pat = u; cur.rows[fill++] = row;
-    }
-    flush();
-    std::stable_sort(ksteps.begin(), ksteps.end(), [](const KStep& x, const KStep& y) { return x.pat.size() > y.pat.size(); });
+    std::vector<KStep> ksteps = uniform_ksteps(a, order);
     // every term-count group gets an even number of k-steps (a k-step of zero rows pads it): the multi-wave main loop is
     // unrolled twice and specialised by term count, so that its phases start at even k-steps
     for (size_t k = 0; k < ksteps.size();) {
@@ -1233,76 +1340,16 @@ int finrom_rom_create(const finrom_rom_desc* a, finrom_rom_t* out) {
     kpat.resize(kpat.size() + 16, 0);                        // the scalar pipeline reads up to two k-steps ahead
     d.tvu_bytes = (int)std::min<size_t>(tvu.size() * sizeof(double), (size_t)0x7FFFFFF0);
 
-    // ---- the same k-steps GROUPED by their leading parameter (proj_main_grouped, NB <= 5) ----------------------------------
-    // A k-step whose rows carry {theta_d} or {1, theta_d} belongs to group d and is accumulated DIVIDED by theta_d: its slab is
-    // T_d (no arithmetic at all) or T_d + (1/theta_d) T_0 (one multiply-add per block); the accumulators are rescaled where the
-    // group changes -- by (theta_d / theta_e)^2 between groups d and e, by theta_d^2 after the last -- so that the sum is the
-    // one the ungrouped loop forms, up to rounding.  Everything else (rows that touch two parameters, merged leftovers) comes
-    // first, at scale 1, with the usual coefficients.  The per-sample scalars (1, theta, 1 / theta, the rescale factors) are
-    // one row of RomDev::ext, filled by rom_ext_kernel ahead of the projection kernel; the records name them by index.
+    // ---- the same k-steps grouped by their leading parameter (build_grouped_tables above; proj_main_grouped, NB <= 5) ------
     d.n_ext = 0; d.nkg = 0; d.ext_final = 0; d.ext = nullptr;
     if (NB <= 5 && getenv("FINROM_PROJ_UNGROUPED") == nullptr) {
-      struct GStep { int group; std::vector<int> pat; const int* rows; };
-      std::vector<GStep> gs;
-      for (const KStep& ks : ksteps) {
-        if (ks.rows[0] < 0 && ks.rows[1] < 0 && ks.rows[2] < 0 && ks.rows[3] < 0) continue;      // the padding k-steps of the list above
-        int group = 0;
-        std::vector<int> pat = ks.pat;
-        if (pat.size() == 1 && pat[0] != 0) group = pat[0];
-        else if (pat.size() == 2 && (pat[0] == 0) != (pat[1] == 0)) { group = pat[0] ? pat[0] : pat[1]; pat = {group, 0}; }
-        gs.push_back({group, pat, ks.rows});
-      }
-      std::stable_sort(gs.begin(), gs.end(), [](const GStep& x, const GStep& y) { return x.group < y.group; });
-      std::vector<int> groups;
-      for (const GStep& g : gs) if (g.group && (groups.empty() || groups.back() != g.group)) groups.push_back(g.group);
-      const int P = a->P, n_ext = 1 + 2 * P + (int)groups.size() + 1;
-      if (!groups.empty() && n_ext <= 64) {
-        // ext[0] = 1, ext[p] = theta_p, ext[P + p] = 1 / theta_p, then one factor per change of group; as (numerator, denominator, squared)
-        std::vector<int> def(3 * (size_t)n_ext, 0);
-        for (int pp = 1; pp <= P; ++pp) { def[3 * pp] = pp; def[3 * (P + pp) + 1] = pp; }
-        std::vector<int> factor_of(groups.size() + 1);
-        for (size_t g = 0; g <= groups.size(); ++g) {
-          const int e = 1 + 2 * P + (int)g;
-          def[3 * e] = g == 0 ? 0 : groups[g - 1]; def[3 * e + 1] = g == groups.size() ? 0 : groups[g]; def[3 * e + 2] = 1;
-          factor_of[g] = e;
-        }
-        std::vector<double> tvg; std::vector<int> kmg;
-        int slot = 0, prev = 0;
-        bool first = true;
-        for (const GStep& g : gs) {
-          const int nt = (int)g.pat.size();
-          int rec[8] = {slot, nt, 0, 0, 0, 0, 0, 0};
-          for (int t = 0; t < nt; ++t) rec[4 + t] = g.group ? (t == 0 ? 0 : P + g.group) : g.pat[t];
-          if (rec[4] == 0) rec[2] |= 1;                       // the first coefficient is 1: its rows are the slab as they are
-          if (g.group != prev && !first) {                   // (nothing to rescale in front of the very first k-step)
-            const size_t gi = std::find(groups.begin(), groups.end(), g.group) - groups.begin();
-            rec[2] |= 2; rec[3] = factor_of[gi];             // (from scale 1: (1 / theta_d)^2)
-          }
-          prev = g.group; first = false;
-          kmg.insert(kmg.end(), rec, rec + 8);
-          for (int t = 0; t < nt; ++t)
-            for (int q = 0; q < 4; ++q) {
-              const size_t base = tvg.size();
-              tvg.resize(base + rp, 0.0);
-              const int row = g.rows[q];
-              if (row < 0) continue;
-              for (int tt = a->row_ptr[row]; tt < a->row_ptr[row + 1]; ++tt)
-                if (a->term_p[tt] == g.pat[t]) for (int col = 0; col < r; ++col) tvg[base + col] += a->term_val[(size_t)tt * r + col];
-            }
-          slot += nt;
-        }
-        // zero k-steps fill the list up to a multiple of three (the loop rotates three slab buffers) and serve the pipeline's reads
-        // of the records / rows of the k-steps behind the last one
-        int nkg = (int)gs.size();
-        const int zslot = slot;
-        tvg.resize(tvg.size() + (size_t)4 * 4 * rp, 0.0);
-        while (nkg % 3) { int rec[8] = {zslot, 1, 1, 0, 0, 0, 0, 0}; kmg.insert(kmg.end(), rec, rec + 8); ++nkg; }
-        for (int k = 0; k < 8; ++k) { int rec[8] = {zslot, 1, 1, 0, 0, 0, 0, 0}; kmg.insert(kmg.end(), rec, rec + 8); }
-        d.nkg = nkg; d.n_ext = n_ext; d.ext_final = factor_of[groups.size()];
-        d.tvg_bytes = (int)std::min<size_t>(tvg.size() * sizeof(double), (size_t)0x7FFFFFF0);
-        int grc = up(h->owned, &d.tvg, tvg.data(), tvg.size());
-        if (!grc) grc = up(h->owned, &d.kmg, kmg.data(), kmg.size());
-        if (!grc) grc = up(h->owned, &d.ext_def, def.data(), def.size());
+      GroupedTables gt;
+      if (build_grouped_tables(a, ksteps, rp, gt)) {
+        d.nkg = gt.nkg; d.n_ext = gt.n_ext; d.ext_final = gt.ext_final;
+        d.tvg_bytes = (int)std::min<size_t>(gt.tvg.size() * sizeof(double), (size_t)0x7FFFFFF0);
+        int grc = up(h->owned, &d.tvg, gt.tvg.data(), gt.tvg.size());
+        if (!grc) grc = up(h->owned, &d.kmg, gt.kmg.data(), gt.kmg.size());
+        if (!grc) grc = up(h->owned, &d.ext_def, gt.def.data(), gt.def.size());
         if (grc) { finrom_rom_destroy(h); return grc; }
       }
     }

@@ -372,8 +372,9 @@ class RomEngine:
     ``terms``: list of (theta_index, sparse-or-dense [n, r] matrix Psi_p = A_p Phi); theta_index 0 is the
     constant (Robin) term, 1..P the parameters.  Only the non-zero rows of each Psi_p are shipped."""
 
-    def __init__(self, n, r, P, terms, rhs, obs_phi):
-        self.n, self.r, self.P = n, r, P
+    @staticmethod
+    def pack_terms(n, r, terms):
+        """(row_ptr [n + 1], term_p [nterms], term_val [nterms, r]) of finrom_rom_desc: per row of psi its non-zero terms."""
         rows = [[] for _ in range(n)]
         for p, M in terms:
             M = np.asarray(M)
@@ -386,8 +387,12 @@ class RomEngine:
             for p, v in rows[j]:
                 term_p.append(p); term_val.append(v)
             row_ptr[j + 1] = len(term_p)
+        return row_ptr, term_p, np.asarray(term_val, dtype=np.float64).reshape(len(term_p), r)
+
+    def __init__(self, n, r, P, terms, rhs, obs_phi):
+        self.n, self.r, self.P = n, r, P
+        row_ptr, term_p, tv = self.pack_terms(n, r, terms)
         self.nterms = len(term_p)
-        tv = np.asarray(term_val, dtype=np.float64).reshape(self.nterms, r)
         obs_phi = np.ascontiguousarray(obs_phi, dtype=np.float64)
         self.n_obs = obs_phi.shape[0]
         a1, p1 = i32(row_ptr); a2, p2 = i32(term_p); a3, p3 = f64(tv); a4, p4 = f64(rhs); a5, p5 = f64(obs_phi)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FINROM_ABI_VERSION 11
+#define FINROM_ABI_VERSION 12
 
 typedef enum {
   FINROM_OK = 0,
@@ -313,6 +313,15 @@ typedef struct {
 
 int finrom_rom_create(const finrom_rom_desc* desc, finrom_rom_t* out);
 void finrom_rom_destroy(finrom_rom_t h);
+/* HOST ONLY (no device is touched; for tests of the host logic): the GROUPED k-step tables finrom_rom_create builds for r <= 80
+ * (the reference forms psi = A(theta) Phi row by row, rom/averaged_affine_ROM.py:291-297 -- here the rows are
+ * sorted by the sub-domain that scales them and accumulated divided by its conductivity).  Sizes first (kmg = tvg = ext_def =
+ * NULL), then the tables:  kmg [(nkg + 8) x 8] records {first slot, terms, flags (1: first coefficient is 1, 2: multiply the
+ * accumulators by ext[factor] first), factor, ext indices of the <= 4 coefficients};  tvg [n_slots x 4 x rp] table rows
+ * (rp = r rounded up to 16);  ext_def [n_ext x 3]: ext[l] = (theta'[a] / theta'[b]) ^ (1 + squared), theta'[0] = 1;
+ * ext_final: the factor behind the last k-step.  nkg = 0: no grouped form for this descriptor. */
+int finrom_rom_grouped_tables(const finrom_rom_desc* desc, int32_t* nkg, int32_t* n_ext, int32_t* ext_final, int64_t* n_slots,
+                              int32_t* kmg, double* tvg, int32_t* ext_def);
 /* theta [S x P] -> w_r [S x r] (NULL to skip), qoi_r [S x n_obs], info [S] (NULL ok);
  * optional A_r [S x r x r] and B_r [S x r] (the state the reference keeps in
  * self._A_r / self._B_r for its gradients, :296-297) -- NULL to skip. */

@@ -26,7 +26,7 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in finrom.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     lib.finrom_version.restype = ctypes.c_int
-    assert lib.finrom_version() == _ffi.ABI_VERSION == 11
+    assert lib.finrom_version() == _ffi.ABI_VERSION == 12
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -462,3 +462,60 @@ def test_hessian_action_is_the_derivative_of_the_gradient(problems, spaces):
         err.append(np.linalg.norm(H - fd) / np.linalg.norm(fd))
     assert err[0] < 1e-5 and err[1] < 1e-7 and err[1] < err[0] / 50          # O(eps^2)
     assert abs(u2 @ H - u @ fin.hessian_action(k, u2, d)) < 1e-10 * np.linalg.norm(H) * np.linalg.norm(u2)
+
+
+@pytest.mark.parametrize("m,r", [(4, 24), (4, 80), (12, 33)])
+def test_grouped_projection_tables_reproduce_psi_t_psi(m, r):
+    """Host logic of the grouped projection loop (finrom_rom_create -> RomDev::kmg / tvg / ext_def, DESIGN 4b), no GPU: the
+    tables from the host-only entry finrom_rom_grouped_tables, walked in NumPy exactly as proj_main_grouped walks them (slab =
+    first term's rows as they are where the record says so, multiply-adds for the others, accumulators rescaled where a record
+    opens a group and behind the last k-step), must give psi^T psi with psi = (A_robin + sum_i theta_i A_i) Phi -- what the
+    reference forms (rom/averaged_affine_ROM.py:291-297) -- for conductivities over the dataset's two decades."""
+    import ctypes as C
+
+    from bayesianinferencedl_amd import _ffi
+    from bayesianinferencedl_amd.engine import RomEngine
+    from bayesianinferencedl_amd.fom.thermal_fin import get_space
+    V = get_space(None, m=m); ops = V.operators(); n = V.dim()
+    rng = np.random.default_rng(3)
+    phi = np.linalg.qr(rng.standard_normal((n, r)))[0]
+    tables = [ops.csr(ops.robin_vals) @ phi] + [ops.csr(ops.sub_vals[i]) @ phi for i in range(9)]
+    row_ptr, term_p, tv = RomEngine.pack_terms(n, r, list(enumerate(tables)))
+    a1, p1 = _ffi.i32(row_ptr); a2, p2 = _ffi.i32(term_p); a3, p3 = _ffi.f64(tv)
+    d = _ffi.RomDesc(n=n, r=r, P=9, n_obs=0, nterms=len(term_p), row_ptr=p1, term_p=p2, term_val=p3, rhs=None, obs_phi=None)
+    L = _ffi.lib()
+    nkg, n_ext, ext_final, n_slots = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    _ffi.check(L.finrom_rom_grouped_tables(C.byref(d), C.byref(nkg), C.byref(n_ext), C.byref(ext_final), C.byref(n_slots), None, None, None))
+    nkg, n_ext, ext_final, n_slots = nkg.value, n_ext.value, ext_final.value, n_slots.value
+    rp = (r + 15) // 16 * 16
+    assert nkg > 0 and nkg % 3 == 0 and 0 < n_ext <= 64 and 0 < ext_final < n_ext
+    kmg = np.zeros((nkg + 8) * 8, np.int32); tvg = np.zeros(n_slots * 4 * rp); ext_def = np.zeros(n_ext * 3, np.int32)
+    o = [C.c_int32() for _ in range(3)] + [C.c_int64()]
+    _ffi.check(L.finrom_rom_grouped_tables(C.byref(d), *[C.byref(x) for x in o], kmg.ctypes.data_as(_ffi.c_i32p),
+                                           tvg.ctypes.data_as(_ffi.c_f64p), ext_def.ctypes.data_as(_ffi.c_i32p)))
+    kmg = kmg.reshape(-1, 8); tvg = tvg.reshape(n_slots, 4, rp); ext_def = ext_def.reshape(n_ext, 3)
+    assert (kmg[nkg:, 1] == 1).all() and (kmg[nkg:, 2] == 1).all()          # the records behind the list: zero k-steps
+    assert not tvg[kmg[nkg, 0]].any()
+    unit = (kmg[:nkg, 2] & 1) != 0
+    assert unit.mean() > 0.9                                # almost every k-step's first term goes in as loaded
+    if m == 12:                                             # (the survey's mesh: 62 % of the rows lie inside a sub-domain)
+        assert ((kmg[:nkg, 1] == 1) & unit).mean() > 0.5  # ... and more than half of the k-steps need no arithmetic at all
+    assert ((kmg[:nkg, 2] & 2) != 0).sum() <= 10          # one rescaling per sub-domain at most
+    for trial in range(3):
+        theta = np.exp(rng.uniform(np.log(0.1), np.log(10.0), 9))
+        th1 = np.concatenate([[1.0], theta])
+        ext = np.array([(th1[a] / th1[b]) ** (2 if sq else 1) for a, b, sq in ext_def])
+        assert ext[0] == 1.0
+        acc = np.zeros((rp, rp))
+        for slot, nt, flags, fidx, *cf in kmg[:nkg]:
+            if flags & 2:
+                acc *= ext[fidx]
+            slab = tvg[slot].copy() if flags & 1 else ext[cf[0]] * tvg[slot]
+            for t in range(1, nt):
+                slab += ext[cf[t]] * tvg[slot + t]
+            acc += slab.T @ slab
+        acc *= ext[ext_final]
+        psi = sum(th1[p] * tables[p] for p in range(10))
+        want = psi.T @ psi
+        assert np.max(np.abs(acc[:r, :r] - want)) <= 1e-12 * np.abs(want).max()
+        assert not acc[r:].any() and not acc[:, r:].any()
